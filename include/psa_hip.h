@@ -1,0 +1,176 @@
+/*
+ * psa_hip.h -- C ABI of libpsa_hip.so: the MI355X (gfx950) implementation of the
+ * PSA spectral-energy-density hot path.
+ *
+ * The reference (h-walk/PSA) is pure Python and has no FFI of its own; the seam
+ * this library replaces is the private method
+ *
+ *     SEDCalculator._calculate_sed_for_group(k_vectors_3d, group_atom_indices, mean_pos_all)
+ *         -> (T, K, 3) complex64                     src/psa/core/sed_calculator.py:58-84
+ *
+ * plus the per-group |.|^2 accumulation of the incoherent branch of
+ * SEDCalculator.calculate (sed_calculator.py:313-327).  Every entry point is
+ * plain C: opaque context pointer, raw host pointers, sizes; no C++ or torch types.
+ * The ctypes stub that binds it is psa_amd/_hip.py; INTEGRATION.md shows the
+ * ten-line patch that routes the reference's own SEDCalculator through it.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative PSA_E* code on failure;
+ *     psa_last_error() returns the text for the calling thread's last failure;
+ *   - host arrays are C-contiguous, owned by the caller, only read/written
+ *     during the call; device memory, rocFFT plans, streams and RCCL
+ *     communicators are owned by the context;
+ *   - entry points may be called from any host thread (each one selects the
+ *     context's device itself); calls on one context are serialised by an
+ *     internal mutex (the reference GUI calls from worker threads,
+ *     src/psa/gui/psa_gui.py:1015, :2246).
+ */
+#ifndef PSA_HIP_H
+#define PSA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSA_HIP_ABI_VERSION 1
+
+/* error codes */
+#define PSA_OK          0
+#define PSA_EINVAL     -1   /* bad argument (shape, NULL, out-of-range index) */
+#define PSA_EHIP       -2   /* HIP runtime failure            */
+#define PSA_EFFT       -3   /* rocFFT failure                 */
+#define PSA_ERCCL      -4   /* RCCL failure                   */
+#define PSA_ESTATE     -5   /* call sequence violated (e.g. finalize before project) */
+#define PSA_ENOMEM     -6
+
+/* data slots: which resident (T, N, 3) float32 array a projection reads.
+ * sed_calculator.py:69-72 projects velocities, or positions minus their mean. */
+#define PSA_SLOT_VELOCITIES 0
+#define PSA_SLOT_POSITIONS  1
+#define PSA_NUM_SLOTS       2
+
+/* flags for psa_sed_project */
+#define PSA_F_DISPLACEMENTS  0x1  /* data = slot - mean_pos (sed_calculator.py:70)           */
+#define PSA_F_INTENSITY      0x2  /* result = sum_g sum_c |S_g|^2, float32 (T,K)  (:313-327) */
+                                  /* default: complex64 (T,K,3) of the (single) group (:296-311) */
+
+/* projection-kernel selector (diagnostics; PSA_K1_AUTO is the product path) */
+#define PSA_K1_AUTO  0   /* fp32 MFMA tile kernel, variant chosen from K          */
+#define PSA_K1_WAVE  1   /* LDS-staged VALU kernel with wavefront shuffle sums     */
+
+typedef struct psa_ctx psa_ctx;
+
+/* ---- library / context ------------------------------------------------ */
+int         psa_abi_version(void);
+const char* psa_last_error(void);
+int         psa_device_count(int* count);
+int         psa_create(int device, psa_ctx** out);
+int         psa_destroy(psa_ctx* ctx);
+int         psa_synchronize(psa_ctx* ctx);
+int         psa_set_k1(psa_ctx* ctx, int selector);     /* PSA_K1_* */
+/* device name / CU count / HBM bytes of the context's GPU */
+int         psa_device_info(psa_ctx* ctx, char* name, int name_len,
+                            int* compute_units, int64_t* hbm_bytes);
+
+/* ---- trajectory residency ---------------------------------------------
+ * Trajectory.velocities / .positions are (T, N, 3) float32 C-order
+ * (src/psa/core/trajectory.py:20-23); they stay in HBM in exactly that layout. */
+int psa_data_upload(psa_ctx* ctx, int slot, const float* host, int64_t T, int64_t N);
+int psa_data_alloc(psa_ctx* ctx, int slot, int64_t T, int64_t N);
+int psa_data_download(psa_ctx* ctx, int slot, float* host, int64_t t0, int64_t nt);
+int psa_data_release(psa_ctx* ctx, int slot);
+int psa_data_shape(psa_ctx* ctx, int slot, int64_t* T, int64_t* N);
+
+/* Fill a slot, already allocated with psa_data_alloc, with the synthetic
+ * trajectory of psa_amd/synth.py (bit-identical NumPy twin there):
+ *   v[t,a,c] = noise(seed,t,a,c) + sum_m [c==mode_comp[m]] amp[m]*(ct[m,t]*ca[m,a] + st[m,t]*sa[m,a])
+ * tables are (n_modes, T) / (n_modes, N) float32, host. */
+int psa_data_fill_synthetic(psa_ctx* ctx, int slot, uint64_t seed, int n_modes,
+                            const float* amp, const int32_t* mode_comp,
+                            const float* ct, const float* st,
+                            const float* ca, const float* sa);
+
+/* mean over frames of a resident slot, float32 sequential-in-t accumulation then /T:
+ * bit-identical to np.mean(positions, axis=0, dtype=np.float32) (sed_calculator.py:205). */
+int psa_mean_positions(psa_ctx* ctx, int slot, float* mean_host /* (N,3) */);
+
+/* ---- the hot path -------------------------------------------------------
+ * psa_sed_project: for each of the G atom groups, for the K_local k-vectors given,
+ *     P[k,a]   = exp(i * (k . mean_pos[idx[a]]))            float32 FMA chain + sincos
+ *     q[k,c,t] = sum_a  d[t, idx[a], c] * P[k,a]            fp32 MFMA, LDS-staged tiles
+ *     S[k,c,w] = FFT_t(q) / T                               batched rocFFT, in place
+ * and either keeps S of the (single) group as complex64, or accumulates
+ * sum_c |S|^2 over groups as float32 (PSA_F_INTENSITY).  The result stays on the
+ * device, k-major, as rows [k_offset, k_offset+K_local) of a K_total-row slab so
+ * that k-sharded ranks produce contiguous pieces of one array.
+ *
+ *   mean_pos_all : (N, 3) float32 host          (sed_calculator.py:205)
+ *   k_vectors    : (K_local, 3) float32 host    (rows k_offset.. of the full list)
+ *   group_idx    : concatenated atom indices of all groups (int32), or NULL with
+ *                  G = 1 meaning "all N atoms in order"
+ *   group_off    : (G+1) int64 offsets into group_idx (ignored when group_idx NULL)
+ * Without PSA_F_INTENSITY, G must be 1.
+ */
+int psa_sed_project(psa_ctx* ctx, int slot,
+                    const float* mean_pos_all,
+                    const float* k_vectors, int64_t K_local,
+                    int64_t K_total, int64_t k_offset,
+                    const int32_t* group_idx, const int64_t* group_off, int32_t G,
+                    int32_t flags);
+
+/* Transpose the K_total-row slab to the reference's layout -- (T,K,3) complex64
+ * (sed_calculator.py:277) or (T,K) float32 (:280) -- and copy it to out_host
+ * (may be NULL: the result then only exists on the device, see psa_result_*). */
+int psa_sed_finalize(psa_ctx* ctx, void* out_host);
+
+/* one-call convenience: project all K on this device, finalize, copy out */
+int psa_sed_calculate(psa_ctx* ctx, int slot, const float* mean_pos_all,
+                      const float* k_vectors, int64_t K,
+                      const int32_t* group_idx, const int64_t* group_off, int32_t G,
+                      int32_t flags, void* out_host);
+
+/* SED.intensity of the finalized complex result, on the device:
+ * (T,K) float32 = sum_c |S|^2   (src/psa/core/sed.py:22-24) */
+int psa_result_intensity(psa_ctx* ctx, float* out_host /* (T,K) */);
+/* chiral phase, option "C", of components (c1, c2) of the finalized complex
+ * result: (T,K) float32           (sed_calculator.py:344-350) */
+int psa_result_chiral_phase(psa_ctx* ctx, int c1, int c2, float* out_host);
+
+/* stage timings of the last project/finalize on this context, milliseconds:
+ * [0] host->device uploads  [1] phase table  [2] projection  [3] FFT
+ * [4] |.|^2 / scale epilogue  [5] gather (RCCL)  [6] transpose  [7] device->host */
+int psa_last_timings(psa_ctx* ctx, double* ms /* [8] */);
+/* number of projection-kernel launches and their summed duration (HIP events on
+ * the context's stream) since the last call of this function */
+int psa_k1_stats(psa_ctx* ctx, int64_t* launches, double* total_ms);
+
+/* diagnostics for tests: the phase table of one group as (K,N_g) complex64, and the
+ * pre-FFT projection q as (K,3,T) complex64 */
+int psa_debug_phase_table(psa_ctx* ctx, const float* mean_pos_all,
+                          const float* k_vectors, int64_t K,
+                          const int32_t* idx, int64_t n_g, int64_t N,
+                          void* out_host);
+int psa_debug_project_only(psa_ctx* ctx, int slot, const float* mean_pos_all,
+                           const float* k_vectors, int64_t K,
+                           const int32_t* idx, int64_t n_g, int32_t flags,
+                           void* out_host);
+
+/* ---- k-point sharding over the GPUs of a node (one process per GPU) ------
+ * rank 0 calls psa_comm_unique_id and ships the 128 bytes to the other ranks by
+ * any host channel; every rank then calls psa_comm_init.  psa_sed_gather moves each
+ * rank's rows of the slab to `root` over RCCL (xGMI) -- or to every rank when root is
+ * -1 -- as grouped point-to-point transfers; k_offsets/k_counts are the (nranks) row
+ * ranges.  After it, the receiving rank(s) call psa_sed_finalize. */
+#define PSA_UNIQUE_ID_BYTES 128
+int psa_comm_unique_id(void* out /* PSA_UNIQUE_ID_BYTES */);
+int psa_comm_init(psa_ctx* ctx, const void* unique_id, int rank, int nranks);
+int psa_comm_destroy(psa_ctx* ctx);
+int psa_sed_gather(psa_ctx* ctx, int root, const int64_t* k_offsets, const int64_t* k_counts);
+int psa_comm_barrier(psa_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSA_HIP_H */

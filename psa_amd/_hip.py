@@ -1,0 +1,324 @@
+"""
+ctypes binding of libpsa_hip.so (C ABI: include/psa_hip.h).
+
+This is the only door between the Python host code and the GPU.  There is no CPU
+implementation behind it: if the library is not built, or no MI355X is visible, every
+entry raises -- the caller is never silently routed somewhere else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libpsa_hip.so"
+
+SLOT_VELOCITIES, SLOT_POSITIONS = 0, 1
+F_DISPLACEMENTS, F_INTENSITY = 0x1, 0x2
+K1_AUTO, K1_WAVE = 0, 1
+UNIQUE_ID_BYTES = 128
+TIMING_NAMES = ("h2d", "phase", "project", "fft", "epilogue", "gather", "transpose", "d2h")
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_ctx = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/psa_hip.h declares
+SIGNATURES = {
+    "psa_abi_version": (C.c_int, []),
+    "psa_last_error": (C.c_char_p, []),
+    "psa_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "psa_create": (C.c_int, [C.c_int, C.POINTER(_ctx)]),
+    "psa_destroy": (C.c_int, [_ctx]),
+    "psa_synchronize": (C.c_int, [_ctx]),
+    "psa_set_k1": (C.c_int, [_ctx, C.c_int]),
+    "psa_device_info": (C.c_int, [_ctx, C.c_char_p, C.c_int, C.POINTER(C.c_int), _i64p]),
+    "psa_data_upload": (C.c_int, [_ctx, C.c_int, _f32p, C.c_int64, C.c_int64]),
+    "psa_data_alloc": (C.c_int, [_ctx, C.c_int, C.c_int64, C.c_int64]),
+    "psa_data_download": (C.c_int, [_ctx, C.c_int, _f32p, C.c_int64, C.c_int64]),
+    "psa_data_release": (C.c_int, [_ctx, C.c_int]),
+    "psa_data_shape": (C.c_int, [_ctx, C.c_int, _i64p, _i64p]),
+    "psa_data_fill_synthetic": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_int, _f32p, _i32p,
+                                          _f32p, _f32p, _f32p, _f32p]),
+    "psa_mean_positions": (C.c_int, [_ctx, C.c_int, _f32p]),
+    "psa_sed_project": (C.c_int, [_ctx, C.c_int, _f32p, _f32p, C.c_int64, C.c_int64, C.c_int64,
+                                  _i32p, _i64p, C.c_int32, C.c_int32]),
+    "psa_sed_finalize": (C.c_int, [_ctx, C.c_void_p]),
+    "psa_sed_calculate": (C.c_int, [_ctx, C.c_int, _f32p, _f32p, C.c_int64, _i32p, _i64p,
+                                    C.c_int32, C.c_int32, C.c_void_p]),
+    "psa_result_intensity": (C.c_int, [_ctx, _f32p]),
+    "psa_result_chiral_phase": (C.c_int, [_ctx, C.c_int, C.c_int, _f32p]),
+    "psa_last_timings": (C.c_int, [_ctx, C.POINTER(C.c_double)]),
+    "psa_k1_stats": (C.c_int, [_ctx, _i64p, C.POINTER(C.c_double)]),
+    "psa_debug_phase_table": (C.c_int, [_ctx, _f32p, _f32p, C.c_int64, _i32p, C.c_int64,
+                                        C.c_int64, C.c_void_p]),
+    "psa_debug_project_only": (C.c_int, [_ctx, C.c_int, _f32p, _f32p, C.c_int64, _i32p,
+                                         C.c_int64, C.c_int32, C.c_void_p]),
+    "psa_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "psa_comm_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
+    "psa_comm_destroy": (C.c_int, [_ctx]),
+    "psa_sed_gather": (C.c_int, [_ctx, C.c_int, _i64p, _i64p]),
+    "psa_comm_barrier": (C.c_int, [_ctx]),
+}
+
+
+class PsaHipError(RuntimeError):
+    """A libpsa_hip entry point returned a non-zero code."""
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library() -> C.CDLL:
+    """dlopen libpsa_hip.so and bind every declared symbol.  Raises if it is missing."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        path = Path(os.environ.get("PSA_HIP_LIBRARY", LIB_PATH))
+        if not path.exists():
+            raise PsaHipError(
+                f"{path} not found: build it with `make -C psa_amd/csrc` (needs hipcc, gfx950). "
+                "psa_amd has no CPU fallback.")
+        lib = C.CDLL(str(path))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the .so lacks a symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+        return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load_library().psa_last_error().decode("utf-8", "replace")
+        if rc == -1 and "out of bounds" in msg:      # same exception type as the reference
+            raise ValueError(msg)
+        raise PsaHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def _f32(a: np.ndarray):
+    return a.ctypes.data_as(_f32p)
+
+
+def _as_f32(a, shape_tail=None) -> np.ndarray:
+    arr = np.ascontiguousarray(a, dtype=np.float32)
+    if shape_tail is not None and arr.shape[1:] != shape_tail:
+        raise ValueError(f"expected (*,{shape_tail}) array, got {arr.shape}")
+    return arr
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(load_library().psa_device_count(C.byref(n)), "psa_device_count")
+    return n.value
+
+
+def pack_groups(groups: Optional[Sequence[np.ndarray]]):
+    """list of index arrays -> (idx int32, off int64, G) for the ABI; None -> all atoms."""
+    if groups is None:
+        return None, None, 1
+    off = np.zeros(len(groups) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(g) for g in groups])
+    idx = (np.concatenate([np.asarray(g).ravel() for g in groups]) if off[-1] > 0
+           else np.zeros(0, dtype=np.int64))
+    if idx.size and (idx.min() < 0 or idx.max() >= 2 ** 31):
+        raise ValueError("Atom indices in basis out of bounds.")
+    return np.ascontiguousarray(idx, dtype=np.int32), off, len(groups)
+
+
+class Engine:
+    """One HIP context (one GPU, one stream) with trajectory arrays resident in HBM."""
+
+    def __init__(self, device: Optional[int] = None):
+        self._lib = load_library()
+        if device is None:
+            device = int(os.environ.get("PSA_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            n = device_count()
+            if n == 0:
+                raise PsaHipError("no HIP device visible; psa_amd has no CPU fallback")
+            device %= n
+        h = _ctx()
+        _check(self._lib.psa_create(int(device), C.byref(h)), "psa_create")
+        self._h = h
+        self.device = int(device)
+        self._resident = {}          # slot -> (array id, data pointer, shape)
+        self.rank, self.nranks = 0, 1
+
+    # -- lifecycle -------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.psa_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(self._lib.psa_synchronize(self._h), "psa_synchronize")
+
+    def set_k1(self, selector: int):
+        _check(self._lib.psa_set_k1(self._h, selector), "psa_set_k1")
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cu, mem = C.c_int(0), C.c_int64(0)
+        _check(self._lib.psa_device_info(self._h, name, 256, C.byref(cu), C.byref(mem)),
+               "psa_device_info")
+        return {"name": name.value.decode(), "compute_units": cu.value, "hbm_bytes": mem.value}
+
+    # -- trajectory residency --------------------------------------------------------
+    def ensure_resident(self, slot: int, array: np.ndarray):
+        """Upload a (T,N,3) array unless this very array is already in the slot."""
+        if array.ndim != 3 or array.shape[2] != 3:
+            raise ValueError("trajectory array must be (frames, atoms, 3)")
+        a = array if (array.dtype == np.float32 and array.flags.c_contiguous) else \
+            np.ascontiguousarray(array, dtype=np.float32)
+        key = (id(array), a.ctypes.data if a is array else None, a.shape)
+        if self._resident.get(slot) == key and key[1] is not None:
+            return
+        T, N = a.shape[0], a.shape[1]
+        _check(self._lib.psa_data_upload(self._h, slot, _f32(a), T, N), "psa_data_upload")
+        self._resident[slot] = key
+
+    def alloc(self, slot: int, T: int, N: int):
+        _check(self._lib.psa_data_alloc(self._h, slot, T, N), "psa_data_alloc")
+        self._resident[slot] = ("device", None, (T, N, 3))
+
+    def fill_synthetic(self, slot: int, seed: int, amp, comp, ct, st, ca, sa):
+        amp = np.ascontiguousarray(amp, np.float32)
+        comp = np.ascontiguousarray(comp, np.int32)
+        tabs = [np.ascontiguousarray(x, np.float32) for x in (ct, st, ca, sa)]
+        _check(self._lib.psa_data_fill_synthetic(
+            self._h, slot, C.c_uint64(seed), len(amp), _f32(amp), comp.ctypes.data_as(_i32p),
+            *[_f32(t) for t in tabs]), "psa_data_fill_synthetic")
+
+    def download(self, slot: int, t0: int, nt: int) -> np.ndarray:
+        T, N = self.shape(slot)
+        out = np.empty((nt, N, 3), np.float32)
+        _check(self._lib.psa_data_download(self._h, slot, _f32(out), t0, nt), "psa_data_download")
+        return out
+
+    def release(self, slot: int):
+        _check(self._lib.psa_data_release(self._h, slot), "psa_data_release")
+        self._resident.pop(slot, None)
+
+    def shape(self, slot: int):
+        T, N = C.c_int64(0), C.c_int64(0)
+        _check(self._lib.psa_data_shape(self._h, slot, C.byref(T), C.byref(N)), "psa_data_shape")
+        return T.value, N.value
+
+    def mean_positions(self, slot: int) -> np.ndarray:
+        _, N = self.shape(slot)
+        out = np.empty((N, 3), np.float32)
+        _check(self._lib.psa_mean_positions(self._h, slot, _f32(out)), "psa_mean_positions")
+        return out
+
+    # -- the hot path ----------------------------------------------------------------
+    def project(self, slot, mean_pos_all, k_vectors, groups=None, flags=0,
+                K_total=None, k_offset=0):
+        mean = _as_f32(mean_pos_all, (3,))
+        kv = _as_f32(k_vectors, (3,)) if len(k_vectors) else np.zeros((0, 3), np.float32)
+        idx, off, G = pack_groups(groups)
+        K_local = kv.shape[0]
+        _check(self._lib.psa_sed_project(
+            self._h, slot, _f32(mean), _f32(kv), K_local,
+            K_local if K_total is None else K_total, k_offset,
+            idx.ctypes.data_as(_i32p) if idx is not None else None,
+            off.ctypes.data_as(_i64p) if off is not None else None, G, flags),
+            "psa_sed_project")
+
+    def finalize(self, T: int, K: int, intensity: bool, fetch: bool = True) -> Optional[np.ndarray]:
+        if not fetch:
+            _check(self._lib.psa_sed_finalize(self._h, None), "psa_sed_finalize")
+            return None
+        out = (np.empty((T, K), np.float32) if intensity else np.empty((T, K, 3), np.complex64))
+        _check(self._lib.psa_sed_finalize(self._h, out.ctypes.data_as(C.c_void_p)),
+               "psa_sed_finalize")
+        return out
+
+    def calculate(self, slot, mean_pos_all, k_vectors, groups=None, flags=0) -> np.ndarray:
+        T, _ = self.shape(slot)
+        self.project(slot, mean_pos_all, k_vectors, groups, flags)
+        return self.finalize(T, len(k_vectors), bool(flags & F_INTENSITY))
+
+    def result_intensity(self, T: int, K: int) -> np.ndarray:
+        out = np.empty((T, K), np.float32)
+        _check(self._lib.psa_result_intensity(self._h, _f32(out)), "psa_result_intensity")
+        return out
+
+    def result_chiral_phase(self, T: int, K: int, c1: int, c2: int) -> np.ndarray:
+        out = np.empty((T, K), np.float32)
+        _check(self._lib.psa_result_chiral_phase(self._h, c1, c2, _f32(out)),
+               "psa_result_chiral_phase")
+        return out
+
+    def timings(self) -> dict:
+        ms = (C.c_double * 8)()
+        _check(self._lib.psa_last_timings(self._h, ms), "psa_last_timings")
+        return dict(zip(TIMING_NAMES, list(ms)))
+
+    def k1_stats(self):
+        n, ms = C.c_int64(0), C.c_double(0.0)
+        _check(self._lib.psa_k1_stats(self._h, C.byref(n), C.byref(ms)), "psa_k1_stats")
+        return n.value, ms.value
+
+    # -- diagnostics -----------------------------------------------------------------
+    def debug_phase_table(self, mean_pos_all, k_vectors, idx=None) -> np.ndarray:
+        mean = _as_f32(mean_pos_all, (3,))
+        kv = _as_f32(k_vectors, (3,))
+        N = mean.shape[0]
+        ii = None if idx is None else np.ascontiguousarray(idx, np.int32)
+        n_g = N if ii is None else len(ii)
+        out = np.empty((kv.shape[0], n_g), np.complex64)
+        _check(self._lib.psa_debug_phase_table(
+            self._h, _f32(mean), _f32(kv), kv.shape[0],
+            ii.ctypes.data_as(_i32p) if ii is not None else None, n_g, N,
+            out.ctypes.data_as(C.c_void_p)), "psa_debug_phase_table")
+        return out
+
+    def debug_project_only(self, slot, mean_pos_all, k_vectors, idx=None, flags=0) -> np.ndarray:
+        T, N = self.shape(slot)
+        mean = _as_f32(mean_pos_all, (3,))
+        kv = _as_f32(k_vectors, (3,))
+        ii = None if idx is None else np.ascontiguousarray(idx, np.int32)
+        n_g = N if ii is None else len(ii)
+        out = np.empty((kv.shape[0], 3, T), np.complex64)
+        _check(self._lib.psa_debug_project_only(
+            self._h, slot, _f32(mean), _f32(kv), kv.shape[0],
+            ii.ctypes.data_as(_i32p) if ii is not None else None, n_g, flags,
+            out.ctypes.data_as(C.c_void_p)), "psa_debug_project_only")
+        return out
+
+    # -- k-point sharding ------------------------------------------------------------
+    @staticmethod
+    def new_unique_id() -> bytes:
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        _check(load_library().psa_comm_unique_id(buf), "psa_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, nranks: int):
+        buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        _check(self._lib.psa_comm_init(self._h, buf, rank, nranks), "psa_comm_init")
+        self.rank, self.nranks = rank, nranks
+
+    def comm_destroy(self):
+        _check(self._lib.psa_comm_destroy(self._h), "psa_comm_destroy")
+        self.rank, self.nranks = 0, 1
+
+    def gather(self, root: int, k_offsets, k_counts):
+        o = np.ascontiguousarray(k_offsets, np.int64)
+        n = np.ascontiguousarray(k_counts, np.int64)
+        _check(self._lib.psa_sed_gather(self._h, root, o.ctypes.data_as(_i64p),
+                                        n.ctypes.data_as(_i64p)), "psa_sed_gather")
+
+    def barrier(self):
+        _check(self._lib.psa_comm_barrier(self._h), "psa_comm_barrier")

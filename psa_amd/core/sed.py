@@ -1,0 +1,69 @@
+"""
+Result container of the SED path.
+
+Mirror of `psa.core.sed.SED` (reference src/psa/core/sed.py:12-69): same field order
+(constructed positionally at sed_calculator.py:330-336), same `.intensity` semantics
+(including the reference's behaviour on already-summed 2-D data, where the last axis is
+k), and the same six-file `.npy` layout for `save` / `load`.
+"""
+from __future__ import annotations
+
+import logging
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Optional, Tuple
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+_REQUIRED = ("sed", "freqs", "k_points", "k_vectors")
+_OPTIONAL = ("k_grid_shape", "phase")
+
+
+@dataclass
+class SED:
+    sed: np.ndarray                                   # (T,K,3) complex64 or (T,K) float32
+    freqs: np.ndarray                                 # (T,) THz, FFT order
+    k_points: np.ndarray                              # |k| along a path (empty for a grid)
+    k_vectors: np.ndarray                             # (K,3)
+    k_grid_shape: Optional[Tuple[int, ...]] = None    # (n_kx, n_ky) for a grid
+    phase: Optional[np.ndarray] = None                # chiral phase (T,K)
+    is_complex: bool = True
+
+    @property
+    def intensity(self) -> np.ndarray:
+        """sum over the last axis of |sed|^2 as float32 (reference sed.py:22-24)."""
+        return np.sum(np.abs(self.sed) ** 2, axis=-1).astype(np.float32)
+
+    @staticmethod
+    def _file(base_path: Path, field: str) -> Path:
+        return base_path.with_suffix(f".{field}.npy")
+
+    def save(self, base_path: Path):
+        base_path.parent.mkdir(parents=True, exist_ok=True)
+        for field in _REQUIRED:
+            np.save(self._file(base_path, field), getattr(self, field))
+        if self.k_grid_shape is not None:
+            np.save(self._file(base_path, "k_grid_shape"), np.array(self.k_grid_shape))
+        if self.phase is not None:
+            np.save(self._file(base_path, "phase"), self.phase)
+        logger.info("SED data saved: %s.*.npy", base_path.name)
+
+    @staticmethod
+    def load(base_path: Path) -> "SED":
+        if not all(SED._file(base_path, f).exists() for f in _REQUIRED):
+            raise FileNotFoundError(f"Required SED files missing for base: {base_path.name}")
+        loaded = {f: np.load(SED._file(base_path, f)) for f in _REQUIRED}
+        extra = {}
+        for field in _OPTIONAL:
+            path = SED._file(base_path, field)
+            if not path.exists():
+                continue
+            try:
+                value = np.load(path)
+                extra[field] = tuple(int(v) for v in value) if field == "k_grid_shape" else value
+            except Exception as err:   # a damaged optional file is not fatal (sed.py:53-56,63-66)
+                logger.warning("Could not load %s data from %s: %s", field, path.name, err)
+        return SED(loaded["sed"], loaded["freqs"], loaded["k_points"], loaded["k_vectors"],
+                   k_grid_shape=extra.get("k_grid_shape"), phase=extra.get("phase"))

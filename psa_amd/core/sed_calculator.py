@@ -1,0 +1,389 @@
+"""
+SEDCalculator -- host side of the MI355X SED path.
+
+Drop-in for `psa.core.sed_calculator.SEDCalculator` (reference
+src/psa/core/sed_calculator.py): same constructor, same `get_k_path` / `get_k_grid` /
+`calculate` / `calculate_chiral_phase` signatures, attributes (`a1..a3`, `b1..b3`,
+`recip_vecs_prim`, `dt_ps`, `traj`, `use_displacements`) and ValueErrors.  What differs is
+where the arithmetic runs: the reference's `_calculate_sed_for_group` (:58-84, NumPy
+einsum + pocketfft) is replaced by libpsa_hip.so (phase table -> fp32-MFMA projection ->
+batched rocFFT -> epilogue) through `psa_amd._hip.Engine`.  There is no CPU path here.
+
+`calculate_kpath_sed` / `calculate_kgrid_sed` / `calculate_chiral_sed` are the composites
+the reference's README names (README.md:100-140) and its GUI implements privately
+(src/psa/gui/psa_gui.py:923-1017, :2099-2247): k generator -> `calculate` -> optional
+chiral phase -> `SED`.
+"""
+from __future__ import annotations
+
+import logging
+import weakref
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from .. import _hip
+from ..utils.helpers import parse_direction
+from .sed import SED
+from .trajectory import Trajectory
+
+logger = logging.getLogger(__name__)
+
+_MODES = ("coherent", "incoherent")
+# Cartesian components whose phase difference defines chirality about an axis
+# (psa_gui.py:975-980)
+_CHIRAL_PAIR = {"x": (1, 2), "y": (0, 2), "z": (0, 1)}
+
+
+class SEDCalculator:
+    def __init__(self, traj: Trajectory, nx: int, ny: int, nz: int,
+                 use_displacements: bool = False, dt_ps: Optional[float] = None):
+        if not (nx > 0 and ny > 0 and nz > 0):
+            raise ValueError("System dimensions (nx, ny, nz) must be positive.")
+        self.traj = traj
+        self.use_displacements = use_displacements
+
+        # timestep: explicit argument (deprecated in the reference, :26-32) wins
+        if dt_ps is not None:
+            logger.warning("Explicitly providing dt_ps to SEDCalculator is deprecated. "
+                           "The provided dt_ps will override the Trajectory's dt_ps.")
+            self.dt_ps = dt_ps
+        elif getattr(traj, "dt_ps", None) is not None:
+            self.dt_ps = traj.dt_ps
+        else:
+            raise ValueError("Timestep dt_ps not found in Trajectory object and not provided to SEDCalculator.")
+        if self.dt_ps <= 0:
+            raise ValueError("Timestep dt_ps must be positive.")
+
+        # primitive cell = rows of the box matrix divided by the replication counts (:40-41)
+        self.a1, self.a2, self.a3 = (traj.box_matrix[i, :] / n for i, n in enumerate((nx, ny, nz)))
+        if min(np.linalg.norm(v) for v in (self.a1, self.a2, self.a3)) < 1e-9:
+            raise ValueError("One or more primitive vectors (a1,a2,a3) near zero. Check nx,ny,nz or box matrix.")
+        volume = np.abs(np.dot(self.a1, np.cross(self.a2, self.a3)))
+        if np.isclose(volume, 0):
+            cell = np.vstack([self.a1, self.a2, self.a3])
+            if np.linalg.matrix_rank(cell) < 3 or np.isclose(np.linalg.det(cell), 0):
+                raise ValueError(f"Primitive cell vectors coplanar/collinear; volume zero ({volume:.2e}).")
+            logger.warning("Primitive cell volume very small (%.2e).", volume)
+        scale = 2 * np.pi / volume
+        self.b1 = scale * np.cross(self.a2, self.a3)
+        self.b2 = scale * np.cross(self.a3, self.a1)
+        self.b3 = scale * np.cross(self.a1, self.a2)
+        self.recip_vecs_prim = np.vstack([self.b1, self.b2, self.b3]).astype(np.float32)
+
+        self._engine: Optional[_hip.Engine] = None
+        self._shard = None                    # psa_amd.dist.KShardGroup when k-sharding
+        self._mean_cache = None               # (weakref to positions, mean array)
+
+    # ------------------------------------------------------------------ device plumbing
+    @property
+    def engine(self) -> "_hip.Engine":
+        """The GPU context (created on first use; raises if libpsa_hip / a GPU is missing)."""
+        if self._engine is None:
+            self._engine = _hip.Engine()
+        return self._engine
+
+    def attach(self, engine=None, shard_group=None) -> "SEDCalculator":
+        """Use an existing Engine and/or shard the k-points over a `dist.KShardGroup`."""
+        if engine is not None:
+            self._engine = engine
+        if shard_group is not None:
+            self._shard = shard_group
+            self._engine = shard_group.engine
+        return self
+
+    def close(self):
+        if self._engine is not None and self._shard is None:
+            self._engine.close()
+        self._engine = None
+
+    def _mean_positions(self) -> np.ndarray:
+        """np.mean(positions, axis=0, dtype=float32) exactly as the reference (:205); cached
+        per positions array because it is a full host pass over (T,N,3)."""
+        pos = self.traj.positions
+        if self._mean_cache is not None and self._mean_cache[0]() is pos:
+            return self._mean_cache[1]
+        mean = np.mean(pos, axis=0, dtype=np.float32)
+        try:
+            self._mean_cache = (weakref.ref(pos), mean)
+        except TypeError:
+            self._mean_cache = None
+        return mean
+
+    def _data_slot(self):
+        if self.use_displacements:
+            return _hip.SLOT_POSITIONS, self.traj.positions, _hip.F_DISPLACEMENTS
+        return _hip.SLOT_VELOCITIES, self.traj.velocities, 0
+
+    def _device_groups(self, groups: Sequence[np.ndarray]):
+        """None (= all atoms in order, the coalesced fast path) when that is what the single
+        group is; the index lists otherwise."""
+        n = self.traj.n_atoms
+        if len(groups) == 1 and groups[0].size == n and np.array_equal(groups[0], np.arange(n)):
+            return None
+        return [np.asarray(g) for g in groups]
+
+    def _run_device(self, k_vectors: np.ndarray, groups, intensity: bool, mean_pos_all,
+                    fetch: bool = True) -> Optional[np.ndarray]:
+        slot, data, flags = self._data_slot()
+        if intensity:
+            flags |= _hip.F_INTENSITY
+        eng = self.engine
+        eng.ensure_resident(slot, data)
+        K = len(k_vectors)
+        T = self.traj.n_frames
+        if self._shard is not None and self._shard.nranks > 1:
+            return self._shard.run(slot, mean_pos_all, k_vectors, groups, flags, T, fetch)
+        eng.project(slot, mean_pos_all, k_vectors, groups, flags)
+        return eng.finalize(T, K, intensity, fetch)
+
+    # ------------------------------------------------------------------ the seam
+    def _calculate_sed_for_group(self, k_vectors_3d: np.ndarray, group_atom_indices: np.ndarray,
+                                 mean_pos_all: np.ndarray) -> np.ndarray:
+        """Complex SED (T,K,3) of one atom group -- the reference's :58-84, on the GPU."""
+        n_t = self.traj.n_frames
+        idx = np.asarray(group_atom_indices)
+        if idx.size == 0 or len(k_vectors_3d) == 0:
+            return np.zeros((n_t, len(k_vectors_3d), 3), dtype=np.complex64)
+        return self._run_device(np.asarray(k_vectors_3d), self._device_groups([idx]), False,
+                                mean_pos_all)
+
+    # ------------------------------------------------------------------ k generators
+    def get_k_path(self, direction_spec: Union[str, int, float, List[float], Dict[str, float], np.ndarray],
+                   bz_coverage: float, n_k: int, lat_param: Optional[float] = None
+                   ) -> Tuple[np.ndarray, np.ndarray]:
+        """(|k| (n_k,), k (n_k,3)) float32 along a direction (reference :86-125)."""
+        k_hat = parse_direction(direction_spec)
+        if lat_param is None or lat_param <= 1e-6:
+            # extent of the reciprocal cell along k_hat: largest |k_hat . b_i|  (:94-104)
+            proj = [float(abs(np.dot(k_hat, b))) for b in (self.b1, self.b2, self.b3)]
+            extent = max(proj)
+            if extent > 1e-6:
+                logger.info("Using directional reciprocal lattice projection (%.3f 2pi/A) for k-path.", extent)
+            else:
+                len_a1 = np.linalg.norm(self.a1)
+                if not len_a1 > 1e-6:
+                    raise ValueError("Invalid/small lattice_param for k-path & reciprocal projections "
+                                     "too small for auto-detection.")
+                extent = 2 * np.pi / len_a1
+                logger.warning("Reciprocal projections too small, using |a1| fallback.")
+        else:
+            extent = 2 * np.pi / lat_param
+        k_max = bz_coverage * extent
+        if n_k < 1:
+            raise ValueError("n_k (k-points) must be >= 1.")
+        if n_k > 1:
+            k_mags = np.linspace(0, k_max, n_k, dtype=np.float32)
+        else:
+            k_mags = np.array([0.0 if np.isclose(k_max, 0) else k_max], dtype=np.float32)
+        return k_mags, np.outer(k_mags, k_hat).astype(np.float32)
+
+    def get_k_grid(self, plane: str, k_range_x: Tuple[float, float], k_range_y: Tuple[float, float],
+                   n_kx: int, n_ky: int, k_fixed_val: float = 0.0
+                   ) -> Tuple[np.ndarray, np.ndarray, Tuple[int, int]]:
+        """(empty, k (n_kx*n_ky,3) float32, (n_kx,n_ky)); the first range is the slow index
+        (reference :127-180)."""
+        if n_kx <= 0 or n_ky <= 0:
+            raise ValueError("Number of k-points (n_kx, n_ky) must be positive.")
+        # column of the k-vector fed by (first range, second range, fixed value)
+        columns = {"xy": (0, 1, 2), "yz": (1, 2, 0), "zx": (2, 0, 1)}.get(plane.lower())
+        if columns is None:
+            raise ValueError(f"Invalid plane specified: {plane}. Must be 'xy', 'yz', or 'zx'.")
+        first = np.linspace(k_range_x[0], k_range_x[1], n_kx, dtype=np.float32)
+        second = np.linspace(k_range_y[0], k_range_y[1], n_ky, dtype=np.float32)
+        k_vecs = np.empty((n_kx, n_ky, 3), dtype=np.float32)
+        k_vecs[:, :, columns[0]] = first[:, None]
+        k_vecs[:, :, columns[1]] = second[None, :]
+        k_vecs[:, :, columns[2]] = k_fixed_val
+        return np.array([], dtype=np.float32), k_vecs.reshape(-1, 3), (n_kx, n_ky)
+
+    # ------------------------------------------------------------------ atom groups
+    def _resolve_groups(self, basis_atom_indices, basis_atom_types, summation_mode) -> List[np.ndarray]:
+        """Atom-index arrays, one per group, with the reference's precedence and fallbacks
+        (:208-266): types win over indices; flat type lists split per type only when
+        incoherent; groups without atoms are dropped; nothing left -> all atoms."""
+        n_atoms = self.traj.n_atoms
+        groups: List[np.ndarray] = []
+
+        def nested(seq, what):
+            if all(isinstance(v, list) for v in seq):
+                return True
+            if all(isinstance(v, int) for v in seq):
+                return False
+            raise ValueError(f"{what} must be a list of ints or a list of lists of ints.")
+
+        if basis_atom_types is not None:
+            if basis_atom_indices is not None:
+                logger.warning("Both basis_atom_types and basis_atom_indices provided. Using basis_atom_types.")
+            type_sets: List[List[int]] = []
+            if isinstance(basis_atom_types, list) and basis_atom_types:
+                if nested(basis_atom_types, "basis_atom_types"):
+                    type_sets = basis_atom_types
+                elif summation_mode == "incoherent":
+                    type_sets = [[t] for t in basis_atom_types]
+                else:
+                    type_sets = [list(basis_atom_types)]
+            elif isinstance(basis_atom_types, int):
+                type_sets = [[basis_atom_types]]
+            for ts in type_sets:
+                members = np.flatnonzero(np.isin(self.traj.types, ts))
+                if members.size:
+                    groups.append(members)
+                else:
+                    logger.warning("No atoms found for type group %s. Skipping.", ts)
+        elif basis_atom_indices is not None:
+            lists: List[np.ndarray] = []
+            if isinstance(basis_atom_indices, list):
+                if basis_atom_indices:
+                    if nested(basis_atom_indices, "basis_atom_indices"):
+                        lists = [np.asarray(sub, dtype=int) for sub in basis_atom_indices]
+                    else:
+                        lists = [np.asarray(basis_atom_indices, dtype=int)]
+            elif isinstance(basis_atom_indices, np.ndarray):
+                if basis_atom_indices.ndim == 1 and basis_atom_indices.size > 0:
+                    lists = [basis_atom_indices.astype(int)]
+                else:
+                    logger.warning("Unsupported np.ndarray format for basis_atom_indices. "
+                                   "Using all atoms if no other basis defined.")
+            for members in lists:
+                if members.size == 0:
+                    continue
+                if np.any(members >= n_atoms) or np.any(members < 0):
+                    raise ValueError("Atom indices in basis out of bounds.")
+                groups.append(members)
+
+        if not groups:
+            groups.append(np.arange(n_atoms))
+            if summation_mode == "incoherent" and n_atoms > 0:
+                logger.info("Using all atoms. Incoherent sum will effectively be a coherent sum of all atoms.")
+        return groups
+
+    # ------------------------------------------------------------------ calculate
+    def calculate(self, k_points_mags: np.ndarray, k_vectors_3d: np.ndarray,
+                  basis_atom_indices: Optional[Union[List[int], List[List[int]], np.ndarray]] = None,
+                  basis_atom_types: Optional[Union[List[int], List[List[int]]]] = None,
+                  summation_mode: str = 'coherent',
+                  k_grid_shape: Optional[Tuple[int, int]] = None,
+                  k_chunk_size: int = 500) -> SED:
+        """SED of the trajectory at the given k-vectors (reference :182-336).
+
+        coherent (or a single group): `sed` is (T,K,3) complex64; incoherent with several
+        groups: (T,K) float32 = sum_g sum_c |S_g|^2.  `k_chunk_size` is accepted for
+        compatibility; the GPU handles all k-points in one pass over the trajectory
+        instead of re-gathering it per chunk (:287-290), which the reference itself only
+        matches to ~8e-7.
+        """
+        if summation_mode not in _MODES:
+            raise ValueError(f"summation_mode must be 'coherent' or 'incoherent', got {summation_mode}")
+        n_t, n_atoms = self.traj.n_frames, self.traj.n_atoms
+        if n_t == 0 or n_atoms == 0:
+            logger.warning("Cannot calculate SED: 0 frames or 0 atoms.")
+            return SED(np.array([], dtype=np.complex64).reshape(0, 0, 3), np.array([], dtype=np.float32),
+                       k_points_mags, k_vectors_3d, k_grid_shape=k_grid_shape, is_complex=True, phase=None)
+
+        mean_pos_all = self._mean_positions()
+        freqs = np.fft.fftfreq(n_t, d=self.dt_ps)
+        groups = self._resolve_groups(basis_atom_indices, basis_atom_types, summation_mode)
+        is_complex = summation_mode == "coherent" or len(groups) <= 1
+        n_k = len(k_vectors_3d)
+
+        if n_k == 0:
+            logger.warning("k_vectors_3d is empty. Returning SED object with empty SED data.")
+            shape = (n_t, 0, 3) if is_complex else (n_t, 0)
+            data = np.zeros(shape, dtype=np.complex64 if is_complex else np.float32)
+        elif is_complex:
+            # several coherent groups act as their sorted union (:297-298)
+            members = np.unique(np.concatenate(groups)).astype(int) if len(groups) > 1 else groups[0]
+            data = self._run_device(np.asarray(k_vectors_3d), self._device_groups([members]), False,
+                                    mean_pos_all)
+        else:
+            data = self._run_device(np.asarray(k_vectors_3d), self._device_groups(groups), True,
+                                    mean_pos_all)
+        return SED(data, freqs, k_points_mags, k_vectors_3d, k_grid_shape=k_grid_shape,
+                   is_complex=is_complex, phase=None)
+
+    # ------------------------------------------------------------------ chiral phase
+    def calculate_chiral_phase(self, Z1: np.ndarray, Z2: np.ndarray, angle_range_opt: str = "C") -> np.ndarray:
+        """Phase relation of two complex component arrays as float32 (reference :338-371).
+
+        "C": folded difference of arguments in [-pi/2, pi/2]; "A": angle between the two
+        phasors in [0, pi]; "B": signed arcsin of their normalised cross product.  A and B
+        are evaluated here as whole-array float32 operations (the reference walks them in
+        a Python double loop); entries whose |Z|^2 < 1e-18 are 0.
+        """
+        if Z1.shape != Z2.shape:
+            raise ValueError("Z1 and Z2 shapes must match for chiral phase.")
+        if Z1.size == 0:
+            return np.array([], dtype=np.float32).reshape(Z1.shape)
+        if angle_range_opt == "C":
+            diff = np.angle(Z1) - np.angle(Z2)
+            diff = (diff + np.pi) % (2 * np.pi) - np.pi
+            diff = np.where(diff > np.pi / 2, np.pi - diff, diff)
+            diff = np.where(diff < -np.pi / 2, -np.pi - diff, diff)
+            return diff.astype(np.float32)
+        phase = np.zeros(Z1.shape, dtype=np.float32)
+        if angle_range_opt not in ("A", "B"):
+            logger.warning("Unknown angle_range_opt '%s'. Angle=0.", angle_range_opt)
+            return phase
+        re1, im1 = np.float32(1) * Z1.real, np.float32(1) * Z1.imag
+        re2, im2 = np.float32(1) * Z2.real, np.float32(1) * Z2.imag
+        sq1, sq2 = re1 * re1 + im1 * im1, re2 * re2 + im2 * im2
+        usable = (sq1 >= 1e-18) & (sq2 >= 1e-18)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            norm = np.sqrt(sq1) * np.sqrt(sq2)
+            if angle_range_opt == "A":
+                full = np.arccos(np.clip((re1 * re2 + im1 * im2) / norm, -1.0, 1.0))
+            else:
+                full = np.arcsin(np.clip((re1 * im2 - im1 * re2) / norm, -1.0, 1.0))
+        phase[usable] = full[usable]
+        return phase
+
+    # ------------------------------------------------------------------ composites
+    def _finish(self, sed: SED, chiral: bool, chiral_axis: str) -> SED:
+        """Attach the option-"C" chiral phase of the component pair for `chiral_axis`
+        (psa_gui.py:970-999); computed on the GPU from the result still resident there."""
+        if not chiral or sed.sed is None or not sed.is_complex:
+            return sed
+        if sed.sed.ndim != 3 or sed.sed.shape[1] == 0:
+            return sed
+        c1, c2 = _CHIRAL_PAIR.get(chiral_axis, _CHIRAL_PAIR["z"])
+        sed.phase = self.engine.result_chiral_phase(sed.sed.shape[0], sed.sed.shape[1], c1, c2)
+        return sed
+
+    def calculate_kpath_sed(self, direction, bz_coverage: float = 1.0, n_k: int = 100,
+                            basis_atom_types=None, summation_mode: str = 'coherent',
+                            basis_atom_indices=None, lat_param: Optional[float] = None,
+                            chiral: bool = False, chiral_axis: str = 'z',
+                            k_chunk_size: int = 500) -> SED:
+        """k-path dispersion in one call (README.md:100-106; psa_gui.py:947-999)."""
+        if chiral and summation_mode != 'coherent':
+            logger.info("Chirality calculation selected, forcing coherent summation mode.")
+            summation_mode = 'coherent'
+        k_mags, k_vecs = self.get_k_path(direction, bz_coverage, n_k, lat_param=lat_param)
+        sed = self.calculate(k_mags, k_vecs, basis_atom_indices=basis_atom_indices,
+                             basis_atom_types=basis_atom_types, summation_mode=summation_mode,
+                             k_chunk_size=k_chunk_size)
+        return self._finish(sed, chiral, chiral_axis)
+
+    def calculate_chiral_sed(self, direction, bz_coverage: float = 1.0, n_k: int = 100,
+                             chiral_axis: str = 'z', **kwargs) -> SED:
+        """README.md:117-122: a k-path SED with the chiral phase attached."""
+        return self.calculate_kpath_sed(direction, bz_coverage, n_k, chiral=True,
+                                        chiral_axis=chiral_axis, **kwargs)
+
+    def calculate_kgrid_sed(self, plane: str = 'xy', k_ranges=(-1.0, 1.0, -1.0, 1.0),
+                            n_kx: int = 20, n_ky: int = 20, k_fixed: float = 0.0,
+                            basis_atom_types=None, summation_mode: str = 'coherent',
+                            basis_atom_indices=None, chiral: bool = False, chiral_axis: str = 'z',
+                            k_chunk_size: int = 500) -> SED:
+        """2-D k-grid SED in one call (README.md:135-140; psa_gui.py:2135-2191).
+        `k_ranges` = (first_min, first_max, second_min, second_max)."""
+        if chiral and summation_mode != 'coherent':
+            logger.info("Chirality calculation selected for K-Grid, forcing coherent summation mode.")
+            summation_mode = 'coherent'
+        k_mags, k_vecs, shape = self.get_k_grid(plane, (k_ranges[0], k_ranges[1]),
+                                                (k_ranges[2], k_ranges[3]), n_kx, n_ky, k_fixed)
+        sed = self.calculate(k_mags, k_vecs, basis_atom_indices=basis_atom_indices,
+                             basis_atom_types=basis_atom_types, summation_mode=summation_mode,
+                             k_grid_shape=shape, k_chunk_size=k_chunk_size)
+        return self._finish(sed, chiral, chiral_axis)

@@ -1,0 +1,170 @@
+// K2 -- epilogues after the batched FFT.  All HBM-streaming: every kernel reads and
+// writes each element once, coalesced on both sides (LDS tile where a transpose is
+// needed).
+//
+//   scale_transpose_c64   S[k,c,w]/T -> out[w,k,c]      ref: sed_calculator.py:83-84, 311
+//   intensity_accumulate  I[k,w] (+)= sum_c |S[k,c,w]/T|^2          ref: :325
+//   transpose_f32         I[k,w] -> out[w,k]                         ref: :327
+//   result_intensity      sum_c |out[w,k,c]|^2                       ref: core/sed.py:22-24
+//   result_chiral_c       folded phase difference of two components  ref: :344-350
+#include "psa_ctx.h"
+
+namespace psa {
+
+constexpr int TT = 64;   // frames per tile
+constexpr int KT = 16;   // k-points per tile
+
+__global__ void __launch_bounds__(256)
+scale_transpose_c64_kernel(const float2* __restrict__ slab, float2* __restrict__ out, int64_t T,
+                           int64_t K) {
+    __shared__ float2 tile[KT * 3][TT + 1];
+    const int64_t t0 = (int64_t)blockIdx.x * TT;
+    const int64_t k0 = (int64_t)blockIdx.y * KT;
+    const int     tid = threadIdx.x;
+    const float   n_t = (float)T;
+    {
+        const int tl = tid & 63;
+#pragma unroll
+        for (int j = 0; j < KT * 3 / 4; ++j) {
+            const int     r = (tid >> 6) + 4 * j;      // row = k_local*3 + c
+            const int64_t k = k0 + r / 3;
+            float2 v = make_float2(0.f, 0.f);
+            if (k < K && t0 + tl < T) {
+                v = slab[(k * 3 + r % 3) * T + t0 + tl];
+                // complex64 / int in NumPy is a true division of both parts (:83)
+                v.x = __fdiv_rn(v.x, n_t);
+                v.y = __fdiv_rn(v.y, n_t);
+            }
+            tile[r][tl] = v;
+        }
+    }
+    __syncthreads();
+    const int kn = (int)((K - k0) < KT ? (K - k0) : KT) * 3;   // valid elements per frame row
+    for (int item = tid; item < TT * KT * 3; item += 256) {
+        const int tl = item / (KT * 3), e = item - tl * (KT * 3);
+        if (e < kn && t0 + tl < T) out[((t0 + tl) * K + k0) * 3 + e] = tile[e][tl];
+    }
+}
+
+int launch_scale_transpose_c64(psa_ctx* c, const float2* d_slab, float2* d_out, int64_t T, int64_t K) {
+    const int64_t gy = (K + KT - 1) / KT;
+    PSA_REQUIRE(gy <= 65535, "too many k-points for one transpose launch");
+    dim3 grid((unsigned)((T + TT - 1) / TT), (unsigned)gy);
+    hipLaunchKernelGGL(scale_transpose_c64_kernel, grid, dim3(256), 0, c->stream, d_slab, d_out, T, K);
+    PSA_HIP_CHECK(hipGetLastError());
+    return PSA_OK;
+}
+
+__global__ void __launch_bounds__(256)
+intensity_accumulate_kernel(const float2* __restrict__ q, float* __restrict__ acc, int64_t T,
+                            int64_t K, int first) {
+    const int64_t total = T * K;
+    const float   n_t = (float)T;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * 256) {
+        const int64_t k = i / T, t = i - k * T;
+        float s = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            const float2 v = q[(k * 3 + cc) * T + t];
+            const float  re = __fdiv_rn(v.x, n_t), im = __fdiv_rn(v.y, n_t);
+            s += re * re + im * im;
+        }
+        acc[i] = first ? s : acc[i] + s;
+    }
+}
+
+int launch_intensity_accumulate(psa_ctx* c, const float2* d_q, float* d_slab_rows, int64_t T,
+                                int64_t K_local, bool first_group) {
+    int64_t blocks = (T * K_local + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(intensity_accumulate_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream,
+                       d_q, d_slab_rows, T, K_local, first_group ? 1 : 0);
+    PSA_HIP_CHECK(hipGetLastError());
+    return PSA_OK;
+}
+
+__global__ void __launch_bounds__(256)
+transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t T, int64_t K) {
+    __shared__ float tile[32][33];
+    const int64_t t0 = (int64_t)blockIdx.x * 32, k0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t k = k0 + ty + 8 * j, t = t0 + tx;
+        tile[ty + 8 * j][tx] = (k < K && t < T) ? in[k * T + t] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t t = t0 + ty + 8 * j, k = k0 + tx;
+        if (k < K && t < T) out[t * K + k] = tile[tx][ty + 8 * j];
+    }
+}
+
+int launch_transpose_f32(psa_ctx* c, const float* d_slab, float* d_out, int64_t T, int64_t K) {
+    const int64_t gy = (K + 31) / 32;
+    PSA_REQUIRE(gy <= 65535, "too many k-points for one transpose launch");
+    dim3 grid((unsigned)((T + 31) / 32), (unsigned)gy);
+    hipLaunchKernelGGL(transpose_f32_kernel, grid, dim3(256), 0, c->stream, d_slab, d_out, T, K);
+    PSA_HIP_CHECK(hipGetLastError());
+    return PSA_OK;
+}
+
+__global__ void __launch_bounds__(256)
+result_intensity_kernel(const float2* __restrict__ out, float* __restrict__ inten, int64_t n_tk) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_tk;
+         i += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            const float2 v = out[3 * i + cc];
+            s += v.x * v.x + v.y * v.y;
+        }
+        inten[i] = s;
+    }
+}
+
+int launch_result_intensity(psa_ctx* c, const float2* d_out, float* d_int, int64_t n_tk) {
+    int64_t blocks = (n_tk + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(result_intensity_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_out,
+                       d_int, n_tk);
+    PSA_HIP_CHECK(hipGetLastError());
+    return PSA_OK;
+}
+
+// Option "C" of calculate_chiral_phase (:344-350), all in float32 like the reference:
+//   d = angle(Z1) - angle(Z2);  d = (d + pi) % (2 pi) - pi;  fold |d| > pi/2 back.
+__global__ void __launch_bounds__(256)
+result_chiral_c_kernel(const float2* __restrict__ out, float* __restrict__ phase, int64_t n_tk, int c1,
+                       int c2) {
+    const float PI = 3.14159265358979323846f, TWO_PI = 6.28318530717958647692f;
+    const float HALF_PI = 1.57079632679489661923f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_tk;
+         i += (int64_t)gridDim.x * 256) {
+        const float2 z1 = out[3 * i + c1], z2 = out[3 * i + c2];
+        float d = atan2f(z1.y, z1.x) - atan2f(z2.y, z2.x);
+        d = d + PI;
+        float m = fmodf(d, TWO_PI);             // Python-style %: result takes the divisor's sign
+        if (m != 0.f && m < 0.f) m += TWO_PI;
+        d = m - PI;
+        if (d > HALF_PI) d = PI - d;
+        else if (d < -HALF_PI) d = -PI - d;
+        phase[i] = d;
+    }
+}
+
+int launch_result_chiral_c(psa_ctx* c, const float2* d_out, float* d_phase, int64_t n_tk, int c1, int c2) {
+    int64_t blocks = (n_tk + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(result_chiral_c_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_out,
+                       d_phase, n_tk, c1, c2);
+    PSA_HIP_CHECK(hipGetLastError());
+    return PSA_OK;
+}
+
+}  // namespace psa

@@ -1,0 +1,156 @@
+// Small streaming kernels around the projection: phase table, mean gather,
+// synthetic-trajectory fill, mean over frames.  All are HBM/latency-bound
+// elementwise work; one thread per output element, coalesced along the fastest axis.
+#include "psa_ctx.h"
+
+namespace psa {
+
+// ---------------------------------------------------------------------------
+// Phase table                                   ref: sed_calculator.py:78
+//   P[k,a] = exp(1j * np.dot(k_vectors, mean_pos_group.T))
+// np.dot on float32 is sgemm; with an inner dimension of 3 OpenBLAS evaluates each
+// entry as the FMA chain fma(kz,rz, fma(ky,ry, kx*rx)) (checked bit-for-bit on the
+// build host, tests/test_oracle_golden.py::test_phase_argument_is_fma_chain), so the
+// argument below is the same float32 number the reference feeds to exp.  Only the
+// sin/cos evaluation differs (<= 2 ulp, ocml vs libm).
+//
+// Layout written: P[m][a], m = 2k (cos) / 2k+1 (sin), row length A_pad, M_pad rows;
+// everything outside (K, n_g) is zero so the tile kernel needs no bounds checks on P.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+phase_table_kernel(const float* __restrict__ kvec, const float* __restrict__ mean_all,
+                   const int* __restrict__ idx, float* __restrict__ P,
+                   int K, int n_g, int A_pad, int M_pad) {
+    const int a = blockIdx.y * 256 + threadIdx.x;      // grid.x runs over k (can be > 65535)
+    const int k = blockIdx.x;
+    if (a >= A_pad || 2 * k >= M_pad) return;
+    float c = 0.f, s = 0.f;
+    if (k < K && a < n_g) {
+        const int   src = idx ? idx[a] : a;
+        const float rx = mean_all[3 * (size_t)src + 0];
+        const float ry = mean_all[3 * (size_t)src + 1];
+        const float rz = mean_all[3 * (size_t)src + 2];
+        const float kx = kvec[3 * k + 0], ky = kvec[3 * k + 1], kz = kvec[3 * k + 2];
+        const float arg = __fmaf_rn(kz, rz, __fmaf_rn(ky, ry, __fmul_rn(kx, rx)));
+        sincosf(arg, &s, &c);
+    }
+    P[(size_t)(2 * k) * A_pad + a]     = c;
+    P[(size_t)(2 * k + 1) * A_pad + a] = s;
+}
+
+int launch_phase_table(psa_ctx* c, const float* d_kvec, const float* d_mean_all, const int* d_idx,
+                       float* d_phase, const ProjGeom& g) {
+    dim3 grid(g.M_pad / 2, (g.A_pad + 255) / 256);
+    hipLaunchKernelGGL(phase_table_kernel, grid, dim3(256), 0, c->stream, d_kvec, d_mean_all, d_idx,
+                       d_phase, g.K, g.n_g, g.A_pad, g.M_pad);
+    PSA_HIP_CHECK(hipGetLastError());
+    return PSA_OK;
+}
+
+// mean positions of the group's atoms, in group order, padded with zeros to A_pad:
+// the tile loader subtracts them from the staged positions (sed_calculator.py:70).
+__global__ void __launch_bounds__(256)
+gather_mean_kernel(const float* __restrict__ mean_all, const int* __restrict__ idx,
+                   float* __restrict__ mean_g, int n_g, int A_pad) {
+    const int j = blockIdx.x * 256 + threadIdx.x;      // float index into (A_pad,3)
+    if (j >= 3 * A_pad) return;
+    const int a = j / 3, comp = j - 3 * a;
+    float v = 0.f;
+    if (a < n_g) v = mean_all[3 * (size_t)(idx ? idx[a] : a) + comp];
+    mean_g[j] = v;
+}
+
+int launch_gather_mean(psa_ctx* c, const float* d_mean_all, const int* d_idx, float* d_mean_g,
+                       const ProjGeom& g) {
+    hipLaunchKernelGGL(gather_mean_kernel, dim3((3 * g.A_pad + 255) / 256), dim3(256), 0, c->stream,
+                       d_mean_all, d_idx, d_mean_g, g.n_g, g.A_pad);
+    PSA_HIP_CHECK(hipGetLastError());
+    return PSA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic trajectory (bench / parity inputs).  NumPy twin: psa_amd/synth.py.
+// Integer hash -> sum of four 16-bit uniforms (Irwin-Hall, ~N(0,1)) -> one float32
+// multiply; plane-wave modes from host-built cos/sin tables with explicitly
+// unfused multiply/add, so both sides produce the same bits.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void __launch_bounds__(256)
+fill_synthetic_kernel(float* __restrict__ v, int64_t T, int64_t N, uint64_t seed, int n_modes,
+                      const float* __restrict__ amp, const int* __restrict__ comp,
+                      const float* __restrict__ ct, const float* __restrict__ st,
+                      const float* __restrict__ ca, const float* __restrict__ sa) {
+    const int64_t total = T * N * 3;
+    const uint64_t key = seed * 0xD1B54A32D192ED03ull;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * 256) {
+        const int64_t ta = i / 3;
+        const int     cc = (int)(i - 3 * ta);
+        const int64_t t = ta / N, a = ta - t * N;
+        const uint64_t h = splitmix64((uint64_t)i ^ key);
+        const int s = (int)(h & 0xFFFF) + (int)((h >> 16) & 0xFFFF) + (int)((h >> 32) & 0xFFFF) +
+                      (int)(h >> 48);
+        float val = __fmul_rn((float)(s - 131070), 1.0f / 37837.0f);
+        for (int m = 0; m < n_modes; ++m) {
+            if (comp[m] == cc) {
+                const float w = __fadd_rn(__fmul_rn(ct[m * T + t], ca[m * N + a]),
+                                          __fmul_rn(st[m * T + t], sa[m * N + a]));
+                val = __fadd_rn(val, __fmul_rn(amp[m], w));
+            }
+        }
+        v[i] = val;
+    }
+}
+
+int launch_fill_synthetic(psa_ctx* c, float* d_v, int64_t T, int64_t N, uint64_t seed, int n_modes,
+                          const float* d_amp, const int* d_comp, const float* d_ct,
+                          const float* d_st, const float* d_ca, const float* d_sa) {
+    const int64_t total = T * N * 3;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fill_synthetic_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_v, T,
+                       N, seed, n_modes, d_amp, d_comp, d_ct, d_st, d_ca, d_sa);
+    PSA_HIP_CHECK(hipGetLastError());
+    return PSA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// mean over frames                               ref: sed_calculator.py:205
+// np.mean(positions, axis=0, dtype=float32) adds frame after frame into one float32
+// accumulator per (atom, component) and divides by T once.  One thread per column,
+// frames in order, adds kept unfused and in sequence; loads are issued 8 frames
+// ahead so the dependent add chain does not serialise HBM.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+mean_over_frames_kernel(const float* __restrict__ x, int64_t T, int64_t cols, float* __restrict__ mean) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    float acc = 0.f;
+    int64_t t = 0;
+    for (; t + 8 <= T; t += 8) {
+        float r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = x[(t + u) * cols + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __fadd_rn(acc, r[u]);
+    }
+    for (; t < T; ++t) acc = __fadd_rn(acc, x[t * cols + j]);
+    mean[j] = __fdiv_rn(acc, (float)T);
+}
+
+int launch_mean_over_frames(psa_ctx* c, const float* d_x, int64_t T, int64_t N, float* d_mean) {
+    const int64_t cols = 3 * N;
+    hipLaunchKernelGGL(mean_over_frames_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0,
+                       c->stream, d_x, T, cols, d_mean);
+    PSA_HIP_CHECK(hipGetLastError());
+    return PSA_OK;
+}
+
+}  // namespace psa

@@ -1,0 +1,172 @@
+// Internal declarations shared by the translation units of libpsa_hip.so.
+// Public surface: include/psa_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "psa_hip.h"
+
+namespace psa {
+
+void set_error(const char* fmt, ...);
+
+#define PSA_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            psa::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,                 \
+                           hipGetErrorString(e_));                                       \
+            return PSA_EHIP;                                                             \
+        }                                                                                \
+    } while (0)
+
+#define PSA_FFT_CHECK(expr)                                                              \
+    do {                                                                                 \
+        rocfft_status s_ = (expr);                                                       \
+        if (s_ != rocfft_status_success) {                                               \
+            psa::set_error("%s:%d: %s -> rocfft_status %d", __FILE__, __LINE__, #expr,   \
+                           (int)s_);                                                     \
+            return PSA_EFFT;                                                             \
+        }                                                                                \
+    } while (0)
+
+#define PSA_NCCL_CHECK(expr)                                                             \
+    do {                                                                                 \
+        ncclResult_t r_ = (expr);                                                        \
+        if (r_ != ncclSuccess) {                                                         \
+            psa::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,                 \
+                           ncclGetErrorString(r_));                                      \
+            return PSA_ERCCL;                                                            \
+        }                                                                                \
+    } while (0)
+
+#define PSA_REQUIRE(cond, ...)                                                           \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            psa::set_error(__VA_ARGS__);                                                 \
+            return PSA_EINVAL;                                                           \
+        }                                                                                \
+    } while (0)
+
+#define PSA_TRY(expr)                                                                    \
+    do {                                                                                 \
+        int rc_ = (expr);                                                                \
+        if (rc_ != PSA_OK) return rc_;                                                   \
+    } while (0)
+
+// grow-only device allocation
+struct DevBuf {
+    void*  ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <class T> T* as() const { return static_cast<T*>(ptr); }
+};
+
+struct FftPlan {
+    rocfft_plan           plan = nullptr;
+    rocfft_execution_info info = nullptr;
+    size_t                work_bytes = 0;
+};
+
+struct DataSlot {
+    DevBuf  buf;
+    int64_t T = 0, N = 0;
+    bool    valid = false;
+};
+
+// stage timing: event pairs recorded on the context's stream, resolved lazily
+struct Timed {
+    int        stage;
+    hipEvent_t e0, e1;
+};
+struct TimingState {
+    std::vector<hipEvent_t> pool;
+    std::vector<Timed>      pending;
+    double                  acc[8] = {};
+    int64_t                 k1_launches = 0;
+    double                  k1_ms = 0.0;
+};
+
+// geometry of one projection launch (see k1_mfma.hip)
+struct ProjGeom {
+    int64_t T = 0;        // frames
+    int64_t N_tot = 0;    // atoms in the resident array
+    int     n_g = 0;      // atoms in this group
+    int     A_pad = 0;    // n_g rounded up to the atom stage (32)
+    int     K = 0;        // k-vectors (rows of the output)
+    int     M_pad = 0;    // 2K rounded up to the variant's M block
+    int     m_blk = 0;    // rows of P per workgroup (variant)
+};
+
+}  // namespace psa
+
+enum { PSA_T_H2D = 0, PSA_T_PHASE, PSA_T_PROJECT, PSA_T_FFT, PSA_T_EPILOGUE, PSA_T_GATHER,
+       PSA_T_TRANSPOSE, PSA_T_D2H, PSA_T_COUNT };
+
+struct psa_ctx {
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex  mu;
+    int         k1_selector = PSA_K1_AUTO;
+    int         compute_units = 0;
+
+    psa::DataSlot slot[PSA_NUM_SLOTS];
+
+    // per-call scratch
+    psa::DevBuf d_kvec, d_mean_all, d_idx, d_mean_g, d_phase, d_qwork, d_fft_work, d_tables;
+    // results
+    psa::DevBuf d_slab;      // k-major: (K_total,3,T) c64  or (K_total,T) f32
+    psa::DevBuf d_out;       // reference layout: (T,K_total,3) c64 or (T,K_total) f32
+    psa::DevBuf d_aux;       // (T,K_total) f32 for intensity / chiral phase of the result
+    int64_t res_T = 0, res_K = 0;
+    bool    res_intensity = false;
+    bool    slab_valid = false, out_valid = false;
+
+    std::map<std::pair<int64_t, int64_t>, psa::FftPlan> plans;   // (T, batch)
+
+    psa::TimingState timing;
+    psa::DevBuf      d_sync;     // one float for the RCCL barrier
+
+    ncclComm_t comm = nullptr;
+    int        rank = 0, nranks = 1;
+};
+
+namespace psa {
+
+// --- kernels_misc.hip
+int launch_phase_table(psa_ctx* c, const float* d_kvec, const float* d_mean_all, const int* d_idx,
+                       float* d_phase, const ProjGeom& g);
+int launch_gather_mean(psa_ctx* c, const float* d_mean_all, const int* d_idx, float* d_mean_g,
+                       const ProjGeom& g);
+int launch_fill_synthetic(psa_ctx* c, float* d_v, int64_t T, int64_t N, uint64_t seed, int n_modes,
+                          const float* d_amp, const int* d_comp, const float* d_ct,
+                          const float* d_st, const float* d_ca, const float* d_sa);
+int launch_mean_over_frames(psa_ctx* c, const float* d_x, int64_t T, int64_t N, float* d_mean);
+
+// --- k1_mfma.hip / k1_wave.hip
+int  k1_mfma_block_rows(int K);                    // M block of the variant chosen for K
+int  launch_k1_mfma(psa_ctx* c, const float* d_v, const float* d_phase, const int* d_idx,
+                    const float* d_mean_g, float2* d_q, const ProjGeom& g, bool displacements);
+int  launch_k1_wave(psa_ctx* c, const float* d_v, const float* d_phase, const int* d_idx,
+                    const float* d_mean_g, float2* d_q, const ProjGeom& g, bool displacements);
+
+// --- k2_epilogue.hip
+int launch_scale_transpose_c64(psa_ctx* c, const float2* d_slab, float2* d_out, int64_t T, int64_t K);
+int launch_intensity_accumulate(psa_ctx* c, const float2* d_q, float* d_slab_rows, int64_t T,
+                                int64_t K_local, bool first_group);
+int launch_transpose_f32(psa_ctx* c, const float* d_slab, float* d_out, int64_t T, int64_t K);
+int launch_result_intensity(psa_ctx* c, const float2* d_out, float* d_int, int64_t n_tk);
+int launch_result_chiral_c(psa_ctx* c, const float2* d_out, float* d_phase, int64_t n_tk, int c1, int c2);
+
+}  // namespace psa

@@ -1,0 +1,143 @@
+"""
+Golden-case table shared by `make_golden.py` (runs the real reference in the build
+container) and by the test-suite (replays the same inputs through the oracle and
+through the HIP path).  Pure data + a deterministic input builder -- no reference
+code lives here.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+A_SI = 5.43
+_BASIS = np.array([[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0],
+                   [.25, .25, .25], [.25, .75, .75], [.75, .25, .75], [.75, .75, .25]])
+
+# name -> how to build a small diamond-cubic trajectory
+TRAJ = {
+    "a": dict(cells=(2, 2, 2), T=128, seed=11, jitter=0.05, tri=False, dt=0.002, third_type=5),
+    "b": dict(cells=(16, 1, 1), T=64, seed=12, jitter=0.05, tri=True, dt=0.001, third_type=0),
+    "c": dict(cells=(1, 1, 3), T=100, seed=13, jitter=0.03, tri=False, dt=0.004, third_type=0),
+}
+
+
+def build_traj(name: str) -> dict:
+    """Deterministic float32 trajectory arrays (positions, velocities, ...)."""
+    spec = TRAJ[name]
+    cx, cy, cz = spec["cells"]
+    rng = np.random.default_rng(spec["seed"])
+    cells = np.array([[i, j, k] for i in range(cx) for j in range(cy) for k in range(cz)], float)
+    frac = (cells[:, None, :] + _BASIS[None, :, :]).reshape(-1, 3)
+    box = np.diag([cx * A_SI, cy * A_SI, cz * A_SI]).astype(np.float64)
+    if spec["tri"]:
+        box[1, 0] = 0.3 * A_SI
+        box[2, 0] = 0.1 * A_SI
+        box[2, 1] = -0.2 * A_SI
+    r0 = (frac / np.array([cx, cy, cz])) @ box           # rows of box are lattice vectors
+    n = r0.shape[0]
+    T = spec["T"]
+    pos = (r0[None] + spec["jitter"] * rng.standard_normal((T, n, 3))).astype(np.float32)
+    vel = rng.standard_normal((T, n, 3)).astype(np.float32)
+    # one planted plane-wave mode so the spectrum has structure
+    t = np.arange(T)[:, None]
+    kx = 2 * np.pi / A_SI * 0.5
+    vel[:, :, 0] += (1.5 * np.cos(2 * np.pi * 5 * t / T - kx * r0[None, :, 0])).astype(np.float32)
+    types = np.tile(np.array([1, 1, 1, 1, 2, 2, 2, 2], np.int32), n // 8)
+    if spec["third_type"]:
+        types[-spec["third_type"]:] = 3
+    return dict(
+        positions=pos, velocities=vel, types=types,
+        timesteps=np.arange(T, dtype=np.float32),
+        box_matrix=box.astype(np.float32),
+        box_lengths=np.array([box[0, 0], box[1, 1], box[2, 2]], np.float32),
+        box_tilts=np.array([box[1, 0], box[2, 0], box[2, 1]], np.float32),
+        dt_ps=spec["dt"], cells=spec["cells"],
+    )
+
+
+def nd(x):
+    """marker: pass this basis as a numpy array rather than a list."""
+    return ("ndarray", list(x))
+
+
+def realise_kw(kw: dict) -> dict:
+    out = {}
+    for k, v in kw.items():
+        if isinstance(v, tuple) and len(v) == 2 and v[0] == "ndarray":
+            v = np.array(v[1])
+        out[k] = v
+    return out
+
+
+_KP = ("path", "100", 1.0, 8, None)
+
+# `calculate` cases: name, traj, k spec, ctor opts, calculate kwargs
+CALC_CASES = [
+    dict(name="coh_all", traj="a", k=_KP),
+    dict(name="coh_types12", traj="a", k=_KP, kw=dict(basis_atom_types=[1, 2])),
+    dict(name="inc_types12", traj="a", k=_KP,
+         kw=dict(basis_atom_types=[1, 2], summation_mode="incoherent")),
+    dict(name="inc_nested_types", traj="a", k=_KP,
+         kw=dict(basis_atom_types=[[1, 2], [3]], summation_mode="incoherent")),
+    dict(name="inc_single_type", traj="a", k=_KP,
+         kw=dict(basis_atom_types=[1], summation_mode="incoherent")),
+    dict(name="inc_all_atoms", traj="a", k=_KP, kw=dict(summation_mode="incoherent")),
+    dict(name="types_fallback_all", traj="a", k=_KP, kw=dict(basis_atom_types=[9])),
+    dict(name="types_partial_missing", traj="a", k=_KP,
+         kw=dict(basis_atom_types=[2, 9], summation_mode="incoherent")),
+    dict(name="type_scalar_int", traj="a", k=_KP, kw=dict(basis_atom_types=2)),
+    dict(name="idx_flat", traj="a", k=_KP, kw=dict(basis_atom_indices=[0, 1, 2, 5, 9])),
+    dict(name="idx_nested_coh", traj="a", k=_KP,
+         kw=dict(basis_atom_indices=[[0, 1, 2], [2, 3]])),
+    dict(name="idx_nested_inc", traj="a", k=_KP,
+         kw=dict(basis_atom_indices=[[0, 1, 2], [2, 3]], summation_mode="incoherent")),
+    dict(name="idx_ndarray_dup_unsorted", traj="a", k=_KP,
+         kw=dict(basis_atom_indices=nd([7, 3, 3, 60]))),
+    dict(name="idx_and_types", traj="a", k=_KP,
+         kw=dict(basis_atom_indices=[0], basis_atom_types=[2])),
+    dict(name="idx_empty_list", traj="a", k=_KP, kw=dict(basis_atom_indices=[])),
+    dict(name="displacements", traj="a", k=_KP, ctor=dict(use_displacements=True)),
+    dict(name="displacements_types_inc", traj="a", k=_KP, ctor=dict(use_displacements=True),
+         kw=dict(basis_atom_types=[1, 2], summation_mode="incoherent")),
+    dict(name="chunked3", traj="a", k=("path", [1, 1, 0], 2.0, 8, None), kw=dict(k_chunk_size=3)),
+    dict(name="large_phase", traj="b", k=("path", [1, 1, 0], 4.0, 16, None)),
+    dict(name="large_phase_latparam", traj="b", k=("path", "x", 4.0, 6, 2.491)),
+    dict(name="nonpow2_T100", traj="c", k=("path", "z", 2.0, 5, None)),
+    dict(name="single_k", traj="c", k=("path", "x", 1.0, 1, None)),
+    dict(name="grid_xy", traj="a", k=("grid", "xy", (-1.5, 1.5), (-1.0, 1.0), 3, 4, 0.25)),
+    dict(name="grid_zx_inc", traj="a", k=("grid", "zx", (-0.5, 1.5), (0.0, 1.0), 2, 3, -0.3),
+         kw=dict(basis_atom_types=[1, 2], summation_mode="incoherent")),
+]
+
+KPATH_CASES = [
+    dict(traj="a", spec="100", cov=1.0, n_k=32, lat=None),
+    dict(traj="a", spec=[1, 1, 0], cov=4.0, n_k=250, lat=None),
+    dict(traj="a", spec="x", cov=1.0, n_k=1, lat=None),
+    dict(traj="a", spec=[1, 1, 0], cov=4.0, n_k=17, lat=2.491),
+    dict(traj="b", spec="100", cov=1.0, n_k=32, lat=None),
+    dict(traj="b", spec=[1, 1, 0], cov=4.0, n_k=25, lat=None),
+    dict(traj="b", spec={"h": 1, "k": 1, "l": 1}, cov=2.0, n_k=9, lat=None),
+    dict(traj="b", spec=30.0, cov=0.5, n_k=7, lat=0.0),
+]
+
+KGRID_CASES = [
+    dict(plane="xy", rx=(-3.5, 3.5), ry=(-3.5, 3.5), nx=5, ny=5, fixed=0.0),
+    dict(plane="XY", rx=(-1.0, 2.0), ry=(0.0, 1.0), nx=3, ny=4, fixed=0.5),
+    dict(plane="yz", rx=(-1.0, 2.0), ry=(0.0, 1.0), nx=4, ny=2, fixed=-0.25),
+    dict(plane="zx", rx=(-1.0, 2.0), ry=(0.0, 1.0), nx=2, ny=3, fixed=1.25),
+    dict(plane="xy", rx=(0.0, 0.0), ry=(1.0, 1.0), nx=1, ny=1, fixed=0.0),
+]
+
+DIRECTION_CASES = ["x", "y", "z", "xy", "yx", "xz", "zx", "yz", "zy", "xyz", "100", "010", "001",
+                   "110", "111", "0,1,0", " 1 0 0 ", "180.0", "-30", 0, 90, 45, 33.3,
+                   [1, 0, 0], (0, 5, 0), [1, 1, 1], [45], [2, -1, 0.5],
+                   {"angle": 30}, {"h": 1, "k": 1, "l": 0}, {"h": 0, "k": 0, "l": 2}, {"k": 3}]
+
+
+def k_from_spec(calc, spec):
+    """Build (k_mags, k_vecs, grid_shape) by calling the calculator's own generators."""
+    if spec[0] == "path":
+        _, d, cov, n_k, lat = spec
+        mags, vecs = calc.get_k_path(d, cov, n_k, lat_param=lat)
+        return mags, vecs, None
+    _, plane, rx, ry, nkx, nky, fixed = spec
+    return calc.get_k_grid(plane, rx, ry, nkx, nky, fixed)
