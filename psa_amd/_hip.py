@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+import weakref
 from pathlib import Path
 from typing import Optional, Sequence
 
@@ -182,16 +183,25 @@ class Engine:
             raise ValueError("trajectory array must be (frames, atoms, 3)")
         a = array if (array.dtype == np.float32 and array.flags.c_contiguous) else \
             np.ascontiguousarray(array, dtype=np.float32)
-        key = (id(array), a.ctypes.data if a is array else None, a.shape)
-        if self._resident.get(slot) == key and key[1] is not None:
+        held = self._resident.get(slot)
+        if (a is array and held is not None and held[0] is not None and held[0]() is array
+                and held[1:] == (a.ctypes.data, a.shape)):
             return
         T, N = a.shape[0], a.shape[1]
         _check(self._lib.psa_data_upload(self._h, slot, _f32(a), T, N), "psa_data_upload")
-        self._resident[slot] = key
+        # a weak reference, not id(): a freed array's id and buffer can be reused
+        self._resident[slot] = (weakref.ref(array) if a is array else None, a.ctypes.data, a.shape)
+
+    def invalidate(self, slot: Optional[int] = None):
+        """Forget what is resident (call after modifying a trajectory array in place)."""
+        if slot is None:
+            self._resident.clear()
+        else:
+            self._resident.pop(slot, None)
 
     def alloc(self, slot: int, T: int, N: int):
         _check(self._lib.psa_data_alloc(self._h, slot, T, N), "psa_data_alloc")
-        self._resident[slot] = ("device", None, (T, N, 3))
+        self._resident[slot] = (None, None, (T, N, 3))
 
     def fill_synthetic(self, slot: int, seed: int, amp, comp, ct, st, ca, sa):
         amp = np.ascontiguousarray(amp, np.float32)

