@@ -290,8 +290,8 @@ int psa_device_info(psa_ctx* c, char* name, int name_len, int* compute_units, in
     hipDeviceProp_t prop;
     PSA_HIP_CHECK(hipGetDeviceProperties(&prop, c->device));
     if (name && name_len > 0) {
-        std::strncpy(name, prop.name, (size_t)name_len - 1);
-        name[name_len - 1] = 0;
+        std::snprintf(name, (size_t)name_len, "%s (%s)", prop.name[0] ? prop.name : "AMD GPU",
+                      prop.gcnArchName);
     }
     if (compute_units) *compute_units = prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
