@@ -157,7 +157,7 @@ int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, ProjGeom* g) {
 
 // phase table + projection of one group into q (K_local,3,T); no FFT
 int project_group(psa_ctx* c, int slot, const int* d_idx, const ProjGeom& g, bool disp, float2* d_q) {
-    PSA_TRY(c->d_phase.reserve((size_t)g.M_pad * g.A_pad * sizeof(float)));
+    PSA_TRY(c->d_phase.reserve(p_table_floats(g.M_pad, g.A_pad) * sizeof(float)));
     {
         StageTimer st(c, PSA_T_PHASE);
         PSA_TRY(launch_phase_table(c, c->d_kvec.as<float>(), c->d_mean_all.as<float>(), d_idx,
@@ -595,18 +595,18 @@ int psa_debug_phase_table(psa_ctx* c, const float* mean_pos_all, const float* k_
     PSA_TRY(upload(c, c->d_kvec, k_vectors, (size_t)K * 3 * sizeof(float)));
     PSA_TRY(upload(c, c->d_mean_all, mean_pos_all, (size_t)N * 3 * sizeof(float)));
     if (idx) PSA_TRY(upload(c, c->d_idx, idx, (size_t)n_g * sizeof(int32_t)));
-    PSA_TRY(c->d_phase.reserve((size_t)g.M_pad * g.A_pad * sizeof(float)));
+    PSA_TRY(c->d_phase.reserve(p_table_floats(g.M_pad, g.A_pad) * sizeof(float)));
     PSA_TRY(launch_phase_table(c, c->d_kvec.as<float>(), c->d_mean_all.as<float>(),
                                idx ? c->d_idx.as<int>() : nullptr, c->d_phase.as<float>(), g));
-    std::vector<float> P((size_t)g.M_pad * g.A_pad);
+    std::vector<float> P(p_table_floats(g.M_pad, g.A_pad));
     PSA_HIP_CHECK(hipMemcpyAsync(P.data(), c->d_phase.ptr, P.size() * sizeof(float),
                                  hipMemcpyDeviceToHost, c->stream));
     PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
     float* o = (float*)out_host;
     for (int64_t k = 0; k < K; ++k)
         for (int64_t a = 0; a < n_g; ++a) {
-            o[2 * (k * n_g + a) + 0] = P[(size_t)(2 * k) * g.A_pad + a];
-            o[2 * (k * n_g + a) + 1] = P[(size_t)(2 * k + 1) * g.A_pad + a];
+            o[2 * (k * n_g + a) + 0] = P[p_tile_index((int)(2 * k), (int)a, g.m_blk, g.A_pad / K1_BA)];
+            o[2 * (k * n_g + a) + 1] = P[p_tile_index((int)(2 * k + 1), (int)a, g.m_blk, g.A_pad / K1_BA)];
         }
     return PSA_OK;
 }

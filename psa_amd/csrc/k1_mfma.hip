@@ -11,21 +11,22 @@
 // Work decomposition (256 threads = 4 wavefronts of 64 per workgroup, 1 workgroup/CU):
 //   workgroup tile : M_BLK = 32*MT*WM rows of P'  x  T_BLK = 32*WN frames x 3 components
 //   wavefront tile : MT row-tiles x 1 frame-tile x 3 components  -> MT*3 accumulators
-//                    of 32x32 (16 VGPRs each); MT=4 -> 192 accumulator VGPRs
-//   atom loop      : stages of BA = 32 atoms, double-buffered in LDS; the next stage's
-//                    global loads are issued before the MFMAs of the current one and
-//                    written to the other LDS buffer after them (one barrier per stage)
+//                    of 32x32 (16 AGPRs each); MT=4 -> 192 accumulator registers
+//   atom loop      : stages of BA = 32 atoms in a 2-deep LDS ring.  Stage s+1 travels
+//                    HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs)
+//                    while the MFMAs of stage s run; one vmcnt(0) + barrier per stage.
 //
 // LDS images (per stage)
-//   Vs[T_BLK][100] : row t holds the 96 floats d[t, a0..a0+31, 0..2] exactly as they lie
-//                    in HBM (component-minor), +4 floats of padding.  A lane reads 48
-//                    contiguous bytes = 4 atoms x 3 components with three ds_read_b128:
-//                    that is the B fragment of all three components for four MFMA
-//                    k-steps -- the (atom, component) interleave costs nothing.
-//   Ps[M_BLK][36]  : row m holds P'[m, a0..a0+31], +4 floats of padding; one ds_read_b128
-//                    = the A fragment of four k-steps.
-//   Row pitches of 25 and 9 sixteen-byte slots (odd) keep every 16-lane ds_read_b128
-//   group on 16 distinct slots of the 256-byte bank row: conflict-free.
+//   Vs[T_BLK][24 slots of 16 B] : row t = the 96 floats d[t, a0..a0+31, 0..2] exactly as
+//       they lie in HBM (component-minor); slot s of row t is stored at physical slot
+//       (s & ~7) | ((s & 7) ^ (t & 7))  (XOR swizzle: LDS-DMA writes 1 KiB linearly per
+//       wave-instruction, so rows cannot be padded; the swizzle goes on the per-lane
+//       SOURCE address and on the read).  A lane's B fragment for four MFMA k-steps x
+//       three components = logical slots 6g+3h .. +2 of its row (48 contiguous bytes in
+//       HBM): three ds_read_b128, at most 2-way bank conflicts.
+//   Ps[M_BLK][36 floats]        : row m = P'[m, a0..a0+31] + 4 pad floats.  The phase kernel
+//       writes P' to HBM already in this tile image, so the DMA is a linear copy; the odd
+//       9-slot pitch makes the A-fragment ds_read_b128 conflict-free.
 //
 // MFMA operand map (32x32x2 f32): lane l supplies A[i = l&31][kk = l>>5] and
 // B[kk = l>>5][j = l&31].  The contraction index may be permuted freely, so k-step s
@@ -45,40 +46,41 @@
 namespace psa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BA   = 32;           // atoms per LDS stage
-constexpr int VROW = 3 * BA + 4;   // floats per Vs row (100 -> 25 slots of 16 B)
-constexpr int PROW = BA + 4;       // floats per Ps row (36 -> 9 slots)
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
 
 template <int MT, int WM, int WN>
 struct K1Cfg {
     static constexpr int M_BLK = 32 * MT * WM;
     static constexpr int T_BLK = 32 * WN;
-    static constexpr int V_STAGE = T_BLK * VROW;   // floats
-    static constexpr int P_STAGE = M_BLK * PROW;
+    static constexpr int V_STAGE = T_BLK * K1_VROW;   // floats
+    static constexpr int P_STAGE = M_BLK * K1_PROW;
     static constexpr int LDS_BYTES = 2 * (V_STAGE + P_STAGE) * 4;
-    static constexpr int V_CHUNKS = T_BLK * 24 / 256;   // 16-byte chunks per thread (VEC loader)
-    static constexpr int V_ITEMS  = T_BLK * BA / 256;   // (t,atom) items per thread (ATOM loader)
-    static constexpr int P_CHUNKS = M_BLK * 8 / 256;
+    static constexpr int V_DMA = T_BLK * 24 / 256;      // V DMA instructions per wave per stage
+    static constexpr int P_CHUNKS = P_STAGE / 4;        // 16-byte chunks in a P' tile
+    static constexpr int P_DMA = (P_CHUNKS + 255) / 256;
+    static constexpr int V_ITEMS = T_BLK * K1_BA / 256; // (t,atom) items per thread (register loader)
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
-    static_assert(P_CHUNKS >= 1, "P tile smaller than one chunk per thread");
+    static_assert((T_BLK * 24) % 256 == 0, "V tile must be whole wave-instructions");
 };
 
-// VEC   : the group is "all atoms in order" and N % 4 == 0 -> rows are 16-byte aligned,
-//         the tile is copied with global_load_dwordx4.
-// !VEC  : arbitrary index list (duplicates, any order) or unaligned N: one (t, atom)
-//         item = three dword loads.
-// DISP  : subtract the group's mean positions while staging (sed_calculator.py:70).
-template <int MT, int WM, int WN, bool VEC, bool DISP>
+__device__ __forceinline__ int v_phys_slot(int s, int row) { return (s & ~7) | ((s & 7) ^ (row & 7)); }
+
+// VDMA  : the group is "all atoms in order", N % 4 == 0, no displacement: the V tile is
+//         copied HBM -> LDS by LDS-DMA.
+// !VDMA : arbitrary index list (duplicates, any order), unaligned N, or displacement mode
+//         (positions - mean, sed_calculator.py:70): one (t, atom) item = three dword loads
+//         through registers.  P' always arrives by DMA.
+template <int MT, int WM, int WN, bool VDMA, bool DISP>
 __global__ void __launch_bounds__(256, 1)
 k1_mfma_kernel(const float* __restrict__ V, const float* __restrict__ P,
                const int* __restrict__ idx, const float* __restrict__ mean_g,
                float2* __restrict__ Q, int64_t T, int64_t N_tot, int n_g, int A_pad, int K,
                int n_mblk, int n_tblk) {
     using C = K1Cfg<MT, WM, WN>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Vs = smem;                       // [2][T_BLK][VROW]
-    float* Ps = smem + 2 * C::V_STAGE;      // [2][M_BLK][PROW]
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_BYTES / 4];
+    float* Vs = smem;                       // [2][T_BLK][96]   swizzled slots
+    float* Ps = smem + 2 * C::V_STAGE;      // [2][M_BLK][36]
 
     // XCD-aware block map: blocks b and b+8 share an XCD (and its L2); give them the
     // M-blocks of one frame tile so the second read of that V tile is an L2 hit.
@@ -94,32 +96,60 @@ k1_mfma_kernel(const float* __restrict__ V, const float* __restrict__ P,
     const int     wm = wave % WM, wn = wave / WM;
     const int     l31 = lane & 31, h = lane >> 5;
     const int64_t t0 = (int64_t)tb * C::T_BLK;
-    const int     m0 = mb * C::M_BLK;
-    const int64_t row_floats = 3 * N_tot;
+    const int     n_stage = A_pad / K1_BA;
+    const float*  Pt = P + (size_t)mb * n_stage * C::P_STAGE;     // this M-block's tile images
 
-    float4 vreg[VEC ? C::V_CHUNKS : 1];
-    float  vx[VEC ? 1 : C::V_ITEMS], vy[VEC ? 1 : C::V_ITEMS], vz[VEC ? 1 : C::V_ITEMS];
-    float4 preg[C::P_CHUNKS];
-
-    auto load_stage = [&](int a0) {
-        if constexpr (VEC) {
+    // ---- V by LDS-DMA: per-lane source offsets (loop invariant) -------------------------
+    // DMA instruction j of this wave fills LDS slots L = (wave*V_DMA + j)*64 + lane.
+    int64_t v_row[VDMA ? C::V_DMA : 1];
+    int     v_s4[VDMA ? C::V_DMA : 1];
+    if constexpr (VDMA) {
 #pragma unroll
-            for (int j = 0; j < C::V_CHUNKS; ++j) {
-                const int     q = tid + 256 * j;
-                const int     row = q / 24, c16 = q - row * 24;
-                const int64_t t = t0 + row;
-                const int     off = 3 * a0 + 4 * c16;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t < T && off < 3 * n_g) {
-                    v = *reinterpret_cast<const float4*>(V + t * row_floats + off);
-                    if constexpr (DISP) {
-                        const float4 m = *reinterpret_cast<const float4*>(mean_g + off);
-                        v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w;
-                    }
-                }
-                vreg[j] = v;
+        for (int j = 0; j < C::V_DMA; ++j) {
+            const int L = (wave * C::V_DMA + j) * 64 + lane;
+            const int row = L / 24, phys = L - row * 24;
+            int64_t   t = t0 + row;
+            if (t >= T) t = T - 1;                              // rows past the end: finite filler
+            v_row[j] = t * 3 * N_tot;
+            v_s4[j] = 4 * v_phys_slot(phys, row);               // the swizzle is an involution
+        }
+    }
+    float vx[VDMA ? 1 : C::V_ITEMS], vy[VDMA ? 1 : C::V_ITEMS], vz[VDMA ? 1 : C::V_ITEMS];
+
+    auto dma_stage = [&](int st, int buf) {
+        // P': linear copy of the tile image, 1 KiB per wave-instruction
+        const float* src = Pt + (size_t)st * C::P_STAGE;
+        float*       dst = Ps + buf * C::P_STAGE;
+#pragma unroll
+        for (int j = 0; j < C::P_DMA; ++j) {
+            const int chunk = (wave * C::P_DMA + j) * 64;        // first 16-byte chunk of this instruction
+            if constexpr (C::P_CHUNKS % 256 == 0) {
+                // every wave issues P_DMA full instructions: straight-line code
+                __builtin_amdgcn_global_load_lds((gbl_void*)(src + 4 * (chunk + lane)),
+                                                 (lds_void*)(dst + 4 * chunk), 16, 0, 0);
+            } else {
+                // wave-uniform outer test; the last instruction of a 32-row tile is half
+                // full, its upper lanes stay masked off (a masked lane writes nothing)
+                if (chunk < C::P_CHUNKS && chunk + lane < C::P_CHUNKS)
+                    __builtin_amdgcn_global_load_lds((gbl_void*)(src + 4 * (chunk + lane)),
+                                                     (lds_void*)(dst + 4 * chunk), 16, 0, 0);
             }
-        } else {
+        }
+        if constexpr (VDMA) {
+            const int a0 = st * K1_BA;
+            float*    vd = Vs + buf * C::V_STAGE;
+#pragma unroll
+            for (int j = 0; j < C::V_DMA; ++j) {
+                // atoms past the group's end carry P' = 0: feed them the stage's first chunk
+                const int s4 = (3 * a0 + v_s4[j] + 3 < 3 * n_g) ? v_s4[j] : 0;
+                __builtin_amdgcn_global_load_lds((gbl_void*)(V + v_row[j] + 3 * a0 + s4),
+                                                 (lds_void*)(vd + (wave * C::V_DMA + j) * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    auto load_items = [&](int a0) {
+        if constexpr (!VDMA) {
 #pragma unroll
             for (int j = 0; j < C::V_ITEMS; ++j) {
                 const int     q = tid + 256 * j;
@@ -138,38 +168,22 @@ k1_mfma_kernel(const float* __restrict__ V, const float* __restrict__ P,
                 vx[j] = x; vy[j] = y; vz[j] = z;
             }
         }
-#pragma unroll
-        for (int j = 0; j < C::P_CHUNKS; ++j) {
-            const int q = tid + 256 * j;
-            const int row = q >> 3, c16 = q & 7;
-            preg[j] = *reinterpret_cast<const float4*>(P + (size_t)(m0 + row) * A_pad + a0 + 4 * c16);
-        }
     };
 
-    auto store_stage = [&](int buf) {
-        float* vs = Vs + buf * C::V_STAGE;
-        float* ps = Ps + buf * C::P_STAGE;
-        if constexpr (VEC) {
-#pragma unroll
-            for (int j = 0; j < C::V_CHUNKS; ++j) {
-                const int q = tid + 256 * j;
-                const int row = q / 24, c16 = q - row * 24;
-                *reinterpret_cast<float4*>(vs + row * VROW + 4 * c16) = vreg[j];
-            }
-        } else {
+    auto store_items = [&](int buf) {
+        if constexpr (!VDMA) {
+            float* vs = Vs + buf * C::V_STAGE;
 #pragma unroll
             for (int j = 0; j < C::V_ITEMS; ++j) {
                 const int q = tid + 256 * j;
                 const int row = q >> 5, al = q & 31;
-                float* d = vs + row * VROW + 3 * al;
-                d[0] = vx[j]; d[1] = vy[j]; d[2] = vz[j];
-            }
-        }
+                const float val[3] = {vx[j], vy[j], vz[j]};
 #pragma unroll
-        for (int j = 0; j < C::P_CHUNKS; ++j) {
-            const int q = tid + 256 * j;
-            const int row = q >> 3, c16 = q & 7;
-            *reinterpret_cast<float4*>(ps + row * PROW + 4 * c16) = preg[j];
+                for (int c = 0; c < 3; ++c) {
+                    const int e = 3 * al + c;                      // float index in the row
+                    vs[row * K1_VROW + 4 * v_phys_slot(e >> 2, row) + (e & 3)] = val[c];
+                }
+            }
         }
     };
 
@@ -181,52 +195,94 @@ k1_mfma_kernel(const float* __restrict__ V, const float* __restrict__ P,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][c][r] = 0.f;
 
-    auto compute_stage = [&](int buf) {
-        const float* vs = Vs + buf * C::V_STAGE + (wn * 32 + l31) * VROW + 12 * h;
-        const float* ps = Ps + buf * C::P_STAGE + (wm * MT * 32 + l31) * PROW + 4 * h;
+    const int vrow = wn * 32 + l31;
+    const int prow = wm * MT * 32 + l31;
+
+    auto load_frags = [&](int buf, int g, float4 (&a)[MT], float4 (&bv)[3]) {
+        const float* ps = Ps + buf * C::P_STAGE + prow * K1_PROW + 4 * h + 8 * g;
 #pragma unroll
-        for (int g = 0; g < BA / 8; ++g) {
-            float4 a[MT];
+        for (int mt = 0; mt < MT; ++mt)
+            a[mt] = *reinterpret_cast<const float4*>(ps + mt * 32 * K1_PROW);
+        const float* vs = Vs + buf * C::V_STAGE + vrow * K1_VROW;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                a[mt] = *reinterpret_cast<const float4*>(ps + mt * 32 * PROW + 8 * g);
-            const float4 b0 = *reinterpret_cast<const float4*>(vs + 24 * g);
-            const float4 b1 = *reinterpret_cast<const float4*>(vs + 24 * g + 4);
-            const float4 b2 = *reinterpret_cast<const float4*>(vs + 24 * g + 8);
-            const float bb[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w,
-                                  b2.x, b2.y, b2.z, b2.w};
+        for (int j = 0; j < 3; ++j)
+            bv[j] = *reinterpret_cast<const float4*>(vs + 4 * v_phys_slot(6 * g + 3 * h + j, vrow));
+    };
+
+    auto mfma_group = [&](const float4 (&a)[MT], const float4 (&bv)[3]) {
+        const float bb[12] = {bv[0].x, bv[0].y, bv[0].z, bv[0].w, bv[1].x, bv[1].y, bv[1].z, bv[1].w,
+                              bv[2].x, bv[2].y, bv[2].z, bv[2].w};
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
+        for (int st = 0; st < 4; ++st) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < 3; ++c) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const float av = st == 0 ? a[mt].x : st == 1 ? a[mt].y : st == 2 ? a[mt].z : a[mt].w;
-                        acc[mt][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bb[3 * st + c],
-                                                                           acc[mt][c], 0, 0, 0);
-                    }
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float av = st == 0 ? a[mt].x : st == 1 ? a[mt].y : st == 2 ? a[mt].z : a[mt].w;
+                    acc[mt][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bb[3 * st + c], acc[mt][c], 0, 0, 0);
                 }
             }
         }
     };
 
-    // atom loop: stage s is computed from LDS buffer s&1 while stage s+1 travels
-    // HBM -> registers -> the other buffer; the last stage is peeled so that the
-    // staging registers are never conditionally live.
-    const int n_stage = A_pad / BA;
-    load_stage(0);
-    store_stage(0);
+    // One stage = 4 k-groups of 8 atoms.  Schedule (pinned with sched_barrier, because the
+    // compiler otherwise sinks the LDS reads next to their first use):
+    //   read g0,g1 | MFMA g0 | read g2 | MFMA g1 | read g3 | DMA(next stage) + MFMA g2 | MFMA g3
+    // - the fragments of group g+1 are in flight behind the 12*MT MFMAs of group g;
+    // - the next stage's LDS-DMA is issued only after this stage's LAST LDS read: hipcc
+    //   (ROCm 7.2) cannot prove that an in-flight LDS-DMA does not alias a later ds_read and
+    //   puts s_waitcnt vmcnt(0) in front of it, so issuing earlier would serialise load and
+    //   compute.  Issued here, the DMA still has two MFMA groups (~6k cycles) to land, and
+    //   its 1-KiB pieces are interleaved one per MFMA (sched_group_barrier) so that their
+    //   issue cost hides in the 64-cycle MFMA shadow.
+    constexpr int N_DMA = (VDMA ? C::V_DMA : 0) + C::P_DMA;
+    auto compute_stage = [&](int buf, bool prefetch, int next_stage) {
+        float4 a0[MT], b0[3], a1[MT], b1[3];
+        load_frags(buf, 0, a0, b0);
+        load_frags(buf, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(buf, 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(buf, 3, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (prefetch) {
+            dma_stage(next_stage, buf ^ 1);
+            load_items(next_stage * K1_BA);
+        }
+        mfma_group(a0, b0);
+#pragma unroll
+        for (int i = 0; i < N_DMA; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // one VMEM (an LDS-DMA piece)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // prologue: stage 0
+    dma_stage(0, 0);
+    load_items(0);
+    store_items(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+
     for (int s = 0; s + 1 < n_stage; ++s) {
-        load_stage((s + 1) * BA);
-        compute_stage(s & 1);
-        store_stage((s & 1) ^ 1);
+        const int buf = s & 1;
+        compute_stage(buf, true, s + 1);
+        store_items(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    compute_stage((n_stage - 1) & 1);
+    compute_stage((n_stage - 1) & 1, false, 0);
 
     // epilogue: complex64 q[k][c][t], 32 consecutive frames per half-wave
     const int64_t t = t0 + wn * 32 + l31;
+    const int     m0 = mb * C::M_BLK;
     if (t < T) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -253,18 +309,16 @@ int k1_mfma_block_rows(int K) {
     return 256;
 }
 
-template <int MT, int WM, int WN, bool VEC, bool DISP>
+template <int MT, int WM, int WN, bool VDMA, bool DISP>
 static int launch_variant(psa_ctx* c, const float* d_v, const float* d_phase, const int* d_idx,
                           const float* d_mean_g, float2* d_q, const ProjGeom& g) {
     using C = K1Cfg<MT, WM, WN>;
-    auto kern = k1_mfma_kernel<MT, WM, WN, VEC, DISP>;
-    PSA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    auto kern = k1_mfma_kernel<MT, WM, WN, VDMA, DISP>;
     const int     n_mblk = g.M_pad / C::M_BLK;
     const int64_t n_tblk = (g.T + C::T_BLK - 1) / C::T_BLK;
     const int64_t grid = ((n_tblk + 7) / 8) * 8 * n_mblk;
     PSA_REQUIRE(grid < (1ll << 31) && n_tblk < (1ll << 31), "projection grid too large");
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), C::LDS_BYTES, c->stream, d_v, d_phase,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, c->stream, d_v, d_phase,
                        d_idx, d_mean_g, d_q, g.T, g.N_tot, g.n_g, g.A_pad, g.K, n_mblk, (int)n_tblk);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
@@ -273,17 +327,15 @@ static int launch_variant(psa_ctx* c, const float* d_v, const float* d_phase, co
 template <int MT, int WM, int WN>
 static int launch_shape(psa_ctx* c, const float* d_v, const float* d_phase, const int* d_idx,
                         const float* d_mean_g, float2* d_q, const ProjGeom& g, bool disp) {
-    const bool vec = (d_idx == nullptr) && (g.N_tot % 4 == 0) && (g.n_g == g.N_tot);
-    if (vec)
-        return disp ? launch_variant<MT, WM, WN, true, true>(c, d_v, d_phase, d_idx, d_mean_g, d_q, g)
-                    : launch_variant<MT, WM, WN, true, false>(c, d_v, d_phase, d_idx, d_mean_g, d_q, g);
+    const bool vdma = !disp && (d_idx == nullptr) && (g.N_tot % 4 == 0) && (g.n_g == g.N_tot);
+    if (vdma) return launch_variant<MT, WM, WN, true, false>(c, d_v, d_phase, d_idx, d_mean_g, d_q, g);
     return disp ? launch_variant<MT, WM, WN, false, true>(c, d_v, d_phase, d_idx, d_mean_g, d_q, g)
                 : launch_variant<MT, WM, WN, false, false>(c, d_v, d_phase, d_idx, d_mean_g, d_q, g);
 }
 
 int launch_k1_mfma(psa_ctx* c, const float* d_v, const float* d_phase, const int* d_idx,
                    const float* d_mean_g, float2* d_q, const ProjGeom& g, bool displacements) {
-    PSA_REQUIRE(g.A_pad % BA == 0 && g.A_pad >= BA, "A_pad must be a positive multiple of %d", BA);
+    PSA_REQUIRE(g.A_pad % K1_BA == 0 && g.A_pad >= K1_BA, "A_pad must be a positive multiple of %d", K1_BA);
     PSA_REQUIRE(g.M_pad % g.m_blk == 0, "M_pad not a multiple of the M block");
     switch (g.m_blk) {
         case 32:  return launch_shape<1, 1, 4>(c, d_v, d_phase, d_idx, d_mean_g, d_q, g, displacements);

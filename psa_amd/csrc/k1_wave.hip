@@ -21,7 +21,7 @@ template <bool DISP>
 __global__ void __launch_bounds__(256)
 k1_wave_kernel(const float* __restrict__ V, const float* __restrict__ P,
                const int* __restrict__ idx, const float* __restrict__ mean_g,
-               float2* __restrict__ Q, int64_t T, int64_t N_tot, int n_g, int A_pad, int K) {
+               float2* __restrict__ Q, int64_t T, int64_t N_tot, int n_g, int A_pad, int K, int m_blk) {
     __shared__ float vs[WK_ATOMS * 3];
     const int64_t t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -59,8 +59,8 @@ k1_wave_kernel(const float* __restrict__ V, const float* __restrict__ P,
                 for (int j = 0; j < WK_K_PER_WAVE; ++j) {
                     const int k = k0 + j;
                     if (k < K) {
-                        const float pc = P[(size_t)(2 * k) * A_pad + a];
-                        const float ps = P[(size_t)(2 * k + 1) * A_pad + a];
+                        const float pc = P[p_tile_index(2 * k, a, m_blk, A_pad / K1_BA)];
+                        const float ps = P[p_tile_index(2 * k + 1, a, m_blk, A_pad / K1_BA)];
                         re[j][0] = fmaf(pc, x, re[j][0]); im[j][0] = fmaf(ps, x, im[j][0]);
                         re[j][1] = fmaf(pc, y, re[j][1]); im[j][1] = fmaf(ps, y, im[j][1]);
                         re[j][2] = fmaf(pc, z, re[j][2]); im[j][2] = fmaf(ps, z, im[j][2]);
@@ -94,10 +94,10 @@ int launch_k1_wave(psa_ctx* c, const float* d_v, const float* d_phase, const int
     dim3 grid((unsigned)g.T, (unsigned)ky);
     if (displacements)
         hipLaunchKernelGGL(k1_wave_kernel<true>, grid, dim3(256), 0, c->stream, d_v, d_phase, d_idx,
-                           d_mean_g, d_q, g.T, g.N_tot, g.n_g, g.A_pad, g.K);
+                           d_mean_g, d_q, g.T, g.N_tot, g.n_g, g.A_pad, g.K, g.m_blk);
     else
         hipLaunchKernelGGL(k1_wave_kernel<false>, grid, dim3(256), 0, c->stream, d_v, d_phase, d_idx,
-                           d_mean_g, d_q, g.T, g.N_tot, g.n_g, g.A_pad, g.K);
+                           d_mean_g, d_q, g.T, g.N_tot, g.n_g, g.A_pad, g.K, g.m_blk);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
 }

@@ -14,13 +14,14 @@ namespace psa {
 // argument below is the same float32 number the reference feeds to exp.  Only the
 // sin/cos evaluation differs (<= 2 ulp, ocml vs libm).
 //
-// Layout written: P[m][a], m = 2k (cos) / 2k+1 (sin), row length A_pad, M_pad rows;
-// everything outside (K, n_g) is zero so the tile kernel needs no bounds checks on P.
+// Layout written: the LDS tile images of the projection kernel (p_tile_index in psa_ctx.h):
+// row m = 2k holds cos, m = 2k+1 holds sin; everything outside (K, n_g) is zero so the
+// tile kernel needs no bounds checks on P' (the 4 pad floats per row are never read).
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 phase_table_kernel(const float* __restrict__ kvec, const float* __restrict__ mean_all,
                    const int* __restrict__ idx, float* __restrict__ P,
-                   int K, int n_g, int A_pad, int M_pad) {
+                   int K, int n_g, int A_pad, int M_pad, int m_blk) {
     const int a = blockIdx.y * 256 + threadIdx.x;      // grid.x runs over k (can be > 65535)
     const int k = blockIdx.x;
     if (a >= A_pad || 2 * k >= M_pad) return;
@@ -34,15 +35,16 @@ phase_table_kernel(const float* __restrict__ kvec, const float* __restrict__ mea
         const float arg = __fmaf_rn(kz, rz, __fmaf_rn(ky, ry, __fmul_rn(kx, rx)));
         sincosf(arg, &s, &c);
     }
-    P[(size_t)(2 * k) * A_pad + a]     = c;
-    P[(size_t)(2 * k + 1) * A_pad + a] = s;
+    const int n_stage = A_pad / K1_BA;
+    P[p_tile_index(2 * k, a, m_blk, n_stage)]     = c;
+    P[p_tile_index(2 * k + 1, a, m_blk, n_stage)] = s;
 }
 
 int launch_phase_table(psa_ctx* c, const float* d_kvec, const float* d_mean_all, const int* d_idx,
                        float* d_phase, const ProjGeom& g) {
     dim3 grid(g.M_pad / 2, (g.A_pad + 255) / 256);
     hipLaunchKernelGGL(phase_table_kernel, grid, dim3(256), 0, c->stream, d_kvec, d_mean_all, d_idx,
-                       d_phase, g.K, g.n_g, g.A_pad, g.M_pad);
+                       d_phase, g.K, g.n_g, g.A_pad, g.M_pad, g.m_blk);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
 }

@@ -98,6 +98,18 @@ struct TimingState {
     double                  k1_ms = 0.0;
 };
 
+// P' (phase table) lives in HBM as the LDS tile images the projection kernel DMAs in:
+//   [M block][atom stage][row in block][K1_PROW floats: 32 atoms + 4 pad]
+constexpr int K1_BA   = 32;   // atoms per LDS stage
+constexpr int K1_VROW = 96;   // floats per staged V row (32 atoms x 3 components)
+constexpr int K1_PROW = 36;   // floats per staged P' row (odd number of 16-byte slots)
+
+__host__ __device__ inline size_t p_tile_index(int m, int a, int m_blk, int n_stage) {
+    return ((size_t)(m / m_blk) * n_stage + (a / K1_BA)) * ((size_t)m_blk * K1_PROW) +
+           (size_t)(m % m_blk) * K1_PROW + (a % K1_BA);
+}
+inline size_t p_table_floats(int M_pad, int A_pad) { return (size_t)M_pad * (A_pad / K1_BA) * K1_PROW; }
+
 // geometry of one projection launch (see k1_mfma.hip)
 struct ProjGeom {
     int64_t T = 0;        // frames
