@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--summation", default="coherent", choices=["coherent", "incoherent"])
+    ap.add_argument("--k-points", type=int, default=0,
+                    help="override the config's k-point count (diagnostics, e.g. 32 = one rank's shard of C3 on 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
@@ -109,6 +111,8 @@ def main():
         exchange = dist.TorchExchange()
 
     spec, req = synth.baseline_spec(args.config)
+    if args.k_points and req["kind"] == "path":
+        req["n_k"] = args.k_points
     r0, types, box = synth.lattice(spec.cells)
     tables = synth.mode_tables(spec, r0)
     T, N = spec.n_frames, spec.n_atoms
@@ -202,9 +206,17 @@ def main():
                          "hbm_frac_if_bytes_bound": (algo_bytes / (k1_avg_ms * 1e-3) / 1e9) / PEAK_HBM_GBS},
             "stages_ms_per_step": {k: v / args.steps for k, v in stages.items()},
         }
+        # HBM traffic of K1 from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # in separate runs; FETCH_SIZE doubled for 16-byte/lane streaming reads as
+        # MI355X_MICROARCH.md prescribes) -- only when this run is the profiled workload
+        pmc = ROOT / "profiles" / "r1b_C3_pmc_fetch_write.json"
+        if args.config == "C3" and K == 256 and world == 1 and not intensity_out and pmc.exists():
+            summ = json.loads(pmc.read_text())["k1_summary"]
+            out["roofline"]["traffic"] = summ["fetch_bytes_corrected_x2"] + summ["write_bytes"]
+            out["roofline"]["traffic_source"] = "profiles/r1b_C3_pmc_fetch_write.json (PMC, per launch)"
         if world == 1 and not args.no_cpu_baseline:
             cores = len(os.sched_getaffinity(0))
-            n_frames = args.cpu_frames or int(min(T, max(64, 2 ** int(np.log2(2.5e10 / (n_sum_atoms * K))))))
+            n_frames = args.cpu_frames or int(min(T, max(64, 2 ** int(np.log2(1.0e11 / (n_sum_atoms * K))))))
             rate, secs, vel, ref_int, mean_sample = cpu_baseline(spec, tables, r0, types, vecs, kw, n_frames)
             # parity of the HIP path on the very same sample
             engine.ensure_resident(_hip.SLOT_VELOCITIES, vel)

@@ -1,0 +1,90 @@
+"""Test double for `psa_amd._hip.Engine`, backed by the CPU oracle.
+
+TEST INFRASTRUCTURE ONLY: it lets the `-m "not gpu"` suite exercise the product's host
+logic (group resolution, flags, k-sharding, result assembly) in a container without a GPU.
+It is injected with `calc.attach(engine=OracleEngine())`; nothing under psa_amd/ knows it
+exists and the product never falls back to it."""
+import numpy as np
+
+from oracle import psa_oracle as O
+from psa_amd import _hip
+
+
+class OracleEngine:
+    def __init__(self, peers=None, rank=0):
+        self.slots, self.calls = {}, []
+        self.rank, self.nranks = rank, 1
+        self._slab = self._meta = self._out = None
+        self._peers = peers                      # shared dict rank -> engine (fake "RCCL")
+
+    # residency
+    def ensure_resident(self, slot, array):
+        self.slots[slot] = np.asarray(array, np.float32)
+
+    def shape(self, slot):
+        return self.slots[slot].shape[:2]
+
+    # hot path
+    def project(self, slot, mean_pos_all, k_vectors, groups=None, flags=0, K_total=None, k_offset=0):
+        self.calls.append(dict(slot=slot, groups=groups, flags=flags, K=len(k_vectors),
+                               K_total=K_total, k_offset=k_offset))
+        data = self.slots[slot]
+        T, N = data.shape[:2]
+        K = len(k_vectors)
+        K_total = K if K_total is None else K_total
+        intensity = bool(flags & _hip.F_INTENSITY)
+        disp = bool(flags & _hip.F_DISPLACEMENTS)
+        if groups is None:
+            groups = [np.arange(N)]
+        if not intensity:
+            assert len(groups) == 1
+        if self._slab is None or self._meta != (T, K_total, intensity):
+            self._slab = np.zeros((K_total, T) if intensity else (K_total, 3, T),
+                                  np.float32 if intensity else np.complex64)
+            self._meta = (T, K_total, intensity)
+        rows = slice(k_offset, k_offset + K)
+        acc = np.zeros((T, K), np.float32)
+        for g in groups:
+            g = np.asarray(g)
+            if g.size == 0:
+                continue
+            if np.any(g < 0) or np.any(g >= N):
+                raise ValueError("Atom indices in basis out of bounds.")
+            s = O.sed_for_group(data, data, np.asarray(k_vectors, np.float32), g,
+                                np.asarray(mean_pos_all, np.float32), use_displacements=disp)
+            if intensity:
+                acc += np.sum(np.abs(s) ** 2, axis=-1)
+            else:
+                self._slab[rows] = s.transpose(1, 2, 0)
+        if intensity:
+            self._slab[rows] = acc.T
+
+    def gather(self, root, k_offsets, k_counts):
+        for r, eng in self._peers.items():
+            if r == self.rank or k_counts[r] == 0:
+                continue
+            if root < 0 or root == self.rank:
+                rows = slice(int(k_offsets[r]), int(k_offsets[r] + k_counts[r]))
+                self._slab[rows] = eng._slab[rows]
+
+    def finalize(self, T, K, intensity, fetch=True):
+        self._out = self._slab.T.copy() if intensity else self._slab.transpose(2, 0, 1).copy()
+        return self._out if fetch else None
+
+    def result_chiral_phase(self, T, K, c1, c2):
+        return O.chiral_phase(self._out[:, :, c1], self._out[:, :, c2], "C")
+
+    def synchronize(self):
+        pass
+
+    def new_unique_id(self):
+        return b"\0" * 128
+
+    def comm_init(self, uid, rank, nranks):
+        self.rank, self.nranks = rank, nranks
+
+    def comm_destroy(self):
+        self.nranks = 1
+
+    def close(self):
+        pass

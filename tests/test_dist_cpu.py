@@ -1,0 +1,122 @@
+"""Multi-process tests of the k-shard path on CPU: world_size-2 `gloo` process groups (and
+the dependency-free TCP rendezvous) drive the product's KShardGroup / SEDCalculator host
+logic; the GPU engine is replaced by the oracle-backed test double whose "RCCL gather" moves
+slab rows through the same exchange."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+HERE = Path(__file__).resolve().parent
+for p in (str(HERE.parent), str(HERE), str(HERE / "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from psa_amd import dist            # noqa: E402
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("n_k, nranks", [(256, 8), (2500, 8), (5, 8), (7, 2), (0, 3), (1, 1), (128, 4)])
+def test_shard_ranges_partition(n_k, nranks):
+    off, cnt = dist.shard_ranges(n_k, nranks)
+    assert off.dtype == np.int64 and cnt.dtype == np.int64 and len(off) == nranks
+    assert cnt.sum() == n_k and cnt.max() - cnt.min() <= 1
+    assert off[0] == 0 and np.array_equal(off[1:], np.cumsum(cnt)[:-1])      # contiguous, ordered
+    with pytest.raises(ValueError):
+        dist.shard_ranges(4, 0)
+
+
+def _sharded_worker(rank, world, port, backend, gather, results):
+    """One rank of a 2-process k-sharded `calculate` (oracle-backed engine)."""
+    import numpy as np
+    import conftest
+    from oracle_engine import OracleEngine
+    from psa_amd import dist as D
+
+    if backend == "gloo":
+        import torch.distributed as td
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                          WORLD_SIZE=str(world))
+        td.init_process_group("gloo", rank=rank, world_size=world)
+        ex = D.TorchExchange()
+    else:
+        ex = D.TcpExchange(rank, world, "127.0.0.1", port)
+
+    class ExchangeEngine(OracleEngine):
+        """slab rows travel through the host exchange instead of RCCL"""
+        def gather(self, root, k_offsets, k_counts):
+            lo, n = int(k_offsets[self.rank]), int(k_counts[self.rank])
+            parts = ex.allgather(self._slab[lo:lo + n])
+            if root < 0 or root == self.rank:
+                for r, rows in enumerate(parts):
+                    self._slab[int(k_offsets[r]):int(k_offsets[r] + k_counts[r])] = rows
+
+    with np.load(conftest.GOLDEN / "traj_a.npz") as z:
+        d = {k: z[k] for k in z.files}
+    d["dt_ps"], d["cells"] = float(d["dt_ps"]), tuple(int(v) for v in d["cells"])
+    eng = ExchangeEngine(rank=rank)
+    group = D.KShardGroup(eng, ex, gather=gather, root=0)
+    calc = conftest.make_calculator(d).attach(shard_group=group)
+    mags, vecs = calc.get_k_path([1, 1, 0], 2.0, 7)               # 7 k-points over 2 ranks: 4 + 3
+    out = {}
+    for name, kw in (("coh", {}), ("inc", dict(basis_atom_types=[1, 2], summation_mode="incoherent"))):
+        sed = calc.calculate(mags, vecs, **kw)
+        out[name] = None if sed.sed is None else np.array(sed.sed)
+        out[name + "_range"] = (eng.calls[-1]["k_offset"], eng.calls[-1]["K"], eng.calls[-1]["K_total"])
+    ex.barrier()
+    results[rank] = out
+    group.close()
+    if backend == "gloo":
+        import torch.distributed as td
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend, gather", [("gloo", "all"), ("gloo", "root"), ("tcp", "all")])
+def test_two_rank_sharded_calculate_equals_unsharded(backend, gather):
+    import conftest
+    from oracle import psa_oracle as O
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        results = mgr.dict()
+        procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, backend, gather, results))
+                 for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+        res = {r: dict(results[r]) for r in range(world)}
+
+    with np.load(conftest.GOLDEN / "traj_a.npz") as z:
+        d = {k: z[k] for k in z.files}
+    calc = conftest.make_calculator(dict(d, dt_ps=float(d["dt_ps"]), cells=tuple(int(v) for v in d["cells"])))
+    _, vecs = calc.get_k_path([1, 1, 0], 2.0, 7)
+    ref_c, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], float(d["dt_ps"]), vecs)
+    ref_i, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], float(d["dt_ps"]), vecs,
+                              basis_atom_types=[1, 2], summation_mode="incoherent")
+    assert res[0]["coh_range"] == (0, 4, 7) and res[1]["coh_range"] == (4, 3, 7)
+    for rank in range(world):
+        if gather == "root" and rank != 0:
+            assert res[rank]["coh"] is None and res[rank]["inc"] is None
+            continue
+        assert conftest.rel_max(res[rank]["coh"], ref_c) <= 2e-6
+        assert conftest.rel_max(res[rank]["inc"], ref_i) <= 2e-6
+
+
+def test_exchange_defaults_single_process():
+    ex = dist.Exchange()
+    assert ex.allgather(3) == [3] and ex.broadcast("x") == "x"
+    ex.barrier()
+    tcp = dist.TcpExchange(0, 1)
+    assert tcp.allgather({"a": 1}) == [{"a": 1}]
+    tcp.close()

@@ -219,3 +219,43 @@ def test_errors_surface_as_python_exceptions(engine, trajs):
         engine.project(0, np.zeros((64, 3), np.float32), vecs, [np.array([1]), np.array([2])], 0)
     empty = calc.calculate(mags[:0], vecs[:0])
     assert empty.sed.shape == (trajs["a"]["positions"].shape[0], 0, 3)
+
+
+def test_single_rank_communicator_and_gather(engine, trajs):
+    """RCCL bring-up on one GPU: unique id, ncclCommInitRank(nranks=1), the gather entry (a
+    no-op exchange with itself) and the barrier all-reduce must work and leave results intact."""
+    from psa_amd import _hip, dist
+    d = trajs["a"]
+    mean = O.mean_positions(d["positions"])
+    _, kv = make_calculator(d).get_k_path("x", 1.0, 6)
+    engine.ensure_resident(0, d["velocities"])
+    uid = engine.new_unique_id()
+    assert len(uid) == _hip.UNIQUE_ID_BYTES
+    engine.comm_init(uid, 0, 1)
+    try:
+        off, cnt = dist.shard_ranges(6, 1)
+        engine.project(0, mean, kv, None, 0, K_total=6, k_offset=0)
+        engine.gather(0, off, cnt)
+        engine.gather(-1, off, cnt)
+        engine.barrier()
+        got = engine.finalize(d["velocities"].shape[0], 6, False)
+    finally:
+        engine.comm_destroy()
+    ref = O.sed_for_group(d["positions"], d["velocities"], kv, np.arange(64), mean)
+    assert rel_max(got, ref) <= TOL
+
+
+def test_k_offset_slab_rows(engine, trajs):
+    """Two projections into one slab (rows 0-3 and 4-6), as two ranks would, equal one pass."""
+    d = trajs["a"]
+    mean = O.mean_positions(d["positions"])
+    _, kv = make_calculator(d).get_k_path([1, 1, 0], 2.0, 7)
+    engine.ensure_resident(0, d["velocities"])
+    T = d["velocities"].shape[0]
+    for flags, groups in ((0, None), (2, [np.arange(0, 64, 2), np.arange(1, 64, 2)])):
+        engine.project(0, mean, kv[:4], groups, flags, K_total=7, k_offset=0)
+        engine.project(0, mean, kv[4:], groups, flags, K_total=7, k_offset=4)
+        parts = engine.finalize(T, 7, bool(flags))
+        engine.project(0, mean, kv, groups, flags)
+        whole = engine.finalize(T, 7, bool(flags))
+        assert rel_max(parts, whole) < 1e-6
