@@ -36,6 +36,8 @@ from psa_amd.core.sed_calculator import SEDCalculator      # noqa: E402
 from psa_amd.core.trajectory import Trajectory             # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md:41-42 (dense, v_mfma_f32_32x32x2_f32)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # ibid. :43 (dense bf16 MFMA)
+SPLIT_MFMA_FLOP_PER_UNIT = 72     # 6 bf16 products per fp32 product in the 3xbf16 split kernel
 PEAK_HBM_GBS = 8000.0             # ibid. :36 (spec; 6.29 TB/s measured copy)
 FLOP_PER_UNIT = 12                # 3 components x (re, im) x FMA per (k, t, atom)  
 
@@ -49,6 +51,9 @@ def parse_args():
     ap.add_argument("--summation", default="coherent", choices=["coherent", "incoherent"])
     ap.add_argument("--k-points", type=int, default=0,
                     help="override the config's k-point count (diagnostics, e.g. 32 = one rank's shard of C3 on 8 GPUs)")
+    ap.add_argument("--k1", default="auto", choices=["auto", "mfma32"],
+                    help="projection kernel: auto = split-precision 3xbf16 MFMA (product default), "
+                         "mfma32 = exact-fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
@@ -119,6 +124,7 @@ def main():
 
     engine = _hip.Engine(local_rank % max(1, _hip.device_count()))
     info = engine.device_info()
+    engine.set_k1(_hip.K1_MFMA32 if args.k1 == "mfma32" else _hip.K1_AUTO)
     synth.fill_device(engine, _hip.SLOT_VELOCITIES, spec, tables)     # V generated in HBM
     group = dist.KShardGroup(engine, exchange, gather="root", root=0)
 
@@ -183,6 +189,17 @@ def main():
             achieved, peak, unit = flops / (k1_avg_ms * 1e-3) / 1e12, PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
         else:
             achieved, peak, unit = algo_bytes / (k1_avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+        split = args.k1 == "auto" and dev_groups is None and N % 4 == 0
+        kernel_name = ("k1_split_kernel (k-projection, 3xbf16 split-precision MFMA, fp32-equivalent)" if split
+                       else "k1_mfma_kernel (k-projection, exact-fp32 MFMA)")
+        roof_note = ("achieved = algorithmic 12 flop/unit over the kernel time, priced against the fp32 "
+                     "matrix-core peak (the precision the path delivers); frac > 1 is the split-precision gain")
+        executed = None
+        if split:
+            ex_rate = SPLIT_MFMA_FLOP_PER_UNIT * per_launch_units / (k1_avg_ms * 1e-3) / 1e12
+            executed = {"what": "bf16 MFMA flop actually issued (6 products per fp32 product)",
+                        "rate": ex_rate, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ex_rate / PEAK_BF16_MFMA_TFLOPS}
         out = {
             "metric": "SED throughput (k-points*timesteps*atoms/s)",
             "value": units * args.steps / elapsed,
@@ -199,18 +216,23 @@ def main():
                        "output": "(T,K) float32 intensity" if intensity_out else "(T,K,3) complex64 + intensity",
                        "parallelism": f"k-shard x{world} (RCCL gather to rank 0)" if world > 1 else "single GPU",
                        "device": info["name"]},
-            "roofline": {"kernel": "k1_mfma_kernel (k-projection, fp32 MFMA)", "bound": bound,
+            "roofline": {"kernel": kernel_name, "bound": bound,
                          "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
                          "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
                          "algorithmic_flop_per_launch": flops, "algorithmic_bytes_per_launch": algo_bytes,
-                         "hbm_frac_if_bytes_bound": (algo_bytes / (k1_avg_ms * 1e-3) / 1e9) / PEAK_HBM_GBS},
+                         "hbm_frac_if_bytes_bound": (algo_bytes / (k1_avg_ms * 1e-3) / 1e9) / PEAK_HBM_GBS,
+                         "note": roof_note},
             "stages_ms_per_step": {k: v / args.steps for k, v in stages.items()},
         }
+        if executed:
+            out["roofline"]["executed_mfma"] = executed
+        out["dtype"] = "f32 (3xbf16 split MFMA, fp32 accumulate)" if split else "f32"
         # HBM traffic of K1 from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # in separate runs; FETCH_SIZE doubled for 16-byte/lane streaming reads as
         # MI355X_MICROARCH.md prescribes) -- only when this run is the profiled workload
         pmc = ROOT / "profiles" / "r1b_C3_pmc_fetch_write.json"
-        if args.config == "C3" and K == 256 and world == 1 and not intensity_out and pmc.exists():
+        if args.config == "C3" and K == 256 and world == 1 and not intensity_out and pmc.exists() \
+                and args.k1 == "mfma32":
             summ = json.loads(pmc.read_text())["k1_summary"]
             out["roofline"]["traffic"] = summ["fetch_bytes_corrected_x2"] + summ["write_bytes"]
             out["roofline"]["traffic_source"] = "profiles/r1b_C3_pmc_fetch_write.json (PMC, per launch)"

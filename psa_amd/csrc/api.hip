@@ -143,25 +143,35 @@ struct GroupView {
     int64_t        n;
 };
 
-int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, ProjGeom* g) {
+int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, const int* d_idx, bool disp,
+              ProjGeom* g) {
     g->T = c->slot[slot].T;
     g->N_tot = c->slot[slot].N;
     PSA_REQUIRE(n_g < (1ll << 30) && K_local < (1ll << 29), "group or k-list too large");
     g->n_g = (int)n_g;
     g->A_pad = (int)((n_g + 31) / 32 * 32);
     g->K = (int)K_local;
-    g->m_blk = k1_mfma_block_rows((int)K_local);
+    // product path: split-precision (3 x bf16) matrix-core kernel whenever the group is the
+    // whole trajectory in order; exact-fp32 MFMA kernel for index lists / displacement mode
+    g->split = c->k1_selector == PSA_K1_AUTO && k1_split_eligible(d_idx, g->N_tot, n_g, disp);
+    g->m_blk = g->split ? k1_split_block_rows((int)K_local) : k1_mfma_block_rows((int)K_local);
     g->M_pad = (int)((2 * K_local + g->m_blk - 1) / g->m_blk * g->m_blk);
     return PSA_OK;
 }
 
 // phase table + projection of one group into q (K_local,3,T); no FFT
 int project_group(psa_ctx* c, int slot, const int* d_idx, const ProjGeom& g, bool disp, float2* d_q) {
-    PSA_TRY(c->d_phase.reserve(p_table_floats(g.M_pad, g.A_pad) * sizeof(float)));
+    const bool split = g.split;
+    PSA_TRY(c->d_phase.reserve(split ? pb_table_bytes(g.M_pad, g.A_pad)
+                                     : p_table_floats(g.M_pad, g.A_pad) * sizeof(float)));
     {
         StageTimer st(c, PSA_T_PHASE);
-        PSA_TRY(launch_phase_table(c, c->d_kvec.as<float>(), c->d_mean_all.as<float>(), d_idx,
-                                   c->d_phase.as<float>(), g));
+        if (split)
+            PSA_TRY(launch_phase_table_split(c, c->d_kvec.as<float>(), c->d_mean_all.as<float>(), d_idx,
+                                             c->d_phase.ptr, g));
+        else
+            PSA_TRY(launch_phase_table(c, c->d_kvec.as<float>(), c->d_mean_all.as<float>(), d_idx,
+                                       c->d_phase.as<float>(), g));
         if (disp) {
             PSA_TRY(c->d_mean_g.reserve((size_t)g.A_pad * 3 * sizeof(float)));
             PSA_TRY(launch_gather_mean(c, c->d_mean_all.as<float>(), d_idx, c->d_mean_g.as<float>(), g));
@@ -170,7 +180,9 @@ int project_group(psa_ctx* c, int slot, const int* d_idx, const ProjGeom& g, boo
     {
         StageTimer st(c, PSA_T_PROJECT);
         const float* d_v = c->slot[slot].buf.as<float>();
-        if (c->k1_selector == PSA_K1_WAVE)
+        if (split)
+            PSA_TRY(launch_k1_split(c, d_v, c->d_phase.ptr, d_q, g));
+        else if (c->k1_selector == PSA_K1_WAVE)
             PSA_TRY(launch_k1_wave(c, d_v, c->d_phase.as<float>(), d_idx, c->d_mean_g.as<float>(), d_q,
                                    g, disp));
         else
@@ -279,7 +291,8 @@ int psa_synchronize(psa_ctx* c) {
 
 int psa_set_k1(psa_ctx* c, int selector) {
     PSA_TRY(enter(c));
-    PSA_REQUIRE(selector == PSA_K1_AUTO || selector == PSA_K1_WAVE, "unknown K1 selector %d", selector);
+    PSA_REQUIRE(selector == PSA_K1_AUTO || selector == PSA_K1_WAVE || selector == PSA_K1_MFMA32,
+                "unknown K1 selector %d", selector);
     Guard g(c);
     c->k1_selector = selector;
     return PSA_OK;
@@ -307,7 +320,11 @@ int psa_data_alloc(psa_ctx* c, int slot, int64_t T, int64_t N) {
     PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
     DataSlot& s = c->slot[slot];
     s.valid = false;
-    PSA_TRY(s.buf.reserve((size_t)T * N * 3 * sizeof(float)));
+    // 512 zeroed bytes behind the array: the split projection kernel's last atom stage may read
+    // up to 31 atoms past the final row (multiplied by a zero phase column)
+    const size_t bytes = (size_t)T * N * 3 * sizeof(float);
+    PSA_TRY(s.buf.reserve(bytes + 512));
+    PSA_HIP_CHECK(hipMemsetAsync((char*)s.buf.ptr + bytes, 0, 512, c->stream));
     s.T = T;
     s.N = N;
     s.valid = true;
@@ -459,7 +476,7 @@ int psa_sed_project(psa_ctx* c, int slot, const float* mean_pos_all, const float
         if (n_g == 0) continue;                                   // sed_calculator.py:64-65, 319-321
         const int* d_idx = group_idx ? c->d_idx.as<int>() + group_off[gi] : nullptr;
         ProjGeom g;
-        PSA_TRY(make_geom(c, slot, K_local, n_g, &g));
+        PSA_TRY(make_geom(c, slot, K_local, n_g, d_idx, disp, &g));
         PSA_TRY(project_group(c, slot, d_idx, g, disp, d_q));
         {
             StageTimer st(c, PSA_T_FFT);
@@ -627,7 +644,7 @@ int psa_debug_project_only(psa_ctx* c, int slot, const float* mean_pos_all, cons
     PSA_TRY(upload(c, c->d_mean_all, mean_pos_all, (size_t)N * 3 * sizeof(float)));
     if (idx) PSA_TRY(upload(c, c->d_idx, idx, (size_t)n_g * sizeof(int32_t)));
     ProjGeom g;
-    PSA_TRY(make_geom(c, slot, K, n_g, &g));
+    PSA_TRY(make_geom(c, slot, K, n_g, idx ? c->d_idx.as<int>() : nullptr, (flags & PSA_F_DISPLACEMENTS) != 0, &g));
     const size_t bytes = (size_t)K * 3 * T * sizeof(float2);
     PSA_TRY(c->d_qwork.reserve(bytes));
     PSA_TRY(project_group(c, slot, idx ? c->d_idx.as<int>() : nullptr, g,

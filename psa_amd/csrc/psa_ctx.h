@@ -119,6 +119,7 @@ struct ProjGeom {
     int     K = 0;        // k-vectors (rows of the output)
     int     M_pad = 0;    // 2K rounded up to the variant's M block
     int     m_blk = 0;    // rows of P per workgroup (variant)
+    bool    split = false;  // split-precision (3 x bf16) kernel + bf16-plane phase table
 };
 
 }  // namespace psa
@@ -172,6 +173,14 @@ int  launch_k1_mfma(psa_ctx* c, const float* d_v, const float* d_phase, const in
                     const float* d_mean_g, float2* d_q, const ProjGeom& g, bool displacements);
 int  launch_k1_wave(psa_ctx* c, const float* d_v, const float* d_phase, const int* d_idx,
                     const float* d_mean_g, float2* d_q, const ProjGeom& g, bool displacements);
+
+// --- k1_split.hip
+bool   k1_split_eligible(const int* d_idx, int64_t N_tot, int64_t n_g, bool displacements);
+int    k1_split_block_rows(int K);
+size_t pb_table_bytes(int M_pad, int A_pad);
+int    launch_phase_table_split(psa_ctx* c, const float* d_kvec, const float* d_mean_all, const int* d_idx,
+                                void* d_phase, const ProjGeom& g);
+int    launch_k1_split(psa_ctx* c, const float* d_v, const void* d_phase, float2* d_q, const ProjGeom& g);
 
 // --- k2_epilogue.hip
 int launch_scale_transpose_c64(psa_ctx* c, const float2* d_slab, float2* d_out, int64_t T, int64_t K);

@@ -65,7 +65,7 @@ def test_mean_positions_is_bit_exact(engine, trajs):
     np.testing.assert_array_equal(engine.mean_positions(1), O.mean_positions(pos))
 
 
-@pytest.mark.parametrize("k1", ["mfma", "wave"])
+@pytest.mark.parametrize("k1", ["auto", "mfma32", "wave"])
 @pytest.mark.parametrize("idx", [None, [3, 9, 9, 60, 1, 17, 33]])
 @pytest.mark.parametrize("disp", [False, True])
 def test_projection_before_fft(engine, trajs, k1, idx, disp):
@@ -73,7 +73,7 @@ def test_projection_before_fft(engine, trajs, k1, idx, disp):
     d = trajs["a"]
     mean = O.mean_positions(d["positions"])
     _, kv = make_calculator(d).get_k_path([1, 1, 0], 2.0, 11)
-    engine.set_k1(_hip.K1_WAVE if k1 == "wave" else _hip.K1_AUTO)
+    engine.set_k1({"auto": _hip.K1_AUTO, "mfma32": _hip.K1_MFMA32, "wave": _hip.K1_WAVE}[k1])
     try:
         src = d["positions"] if disp else d["velocities"]
         engine.ensure_resident(1 if disp else 0, src)
@@ -173,19 +173,23 @@ def test_shapes_against_oracle(engine, n_atoms, n_frames, n_k):
     assert not cx and not got.is_complex and rel_max(got.sed, ref) <= TOL
 
 
-def test_kernels_agree_with_each_other(engine):
-    """fp32-MFMA tile kernel vs the shuffle kernel: different schedules, same q."""
+@pytest.mark.parametrize("n_atoms, n_k", [(300, 37), (1024, 100), (512, 9)])
+def test_kernels_agree_with_each_other(engine, n_atoms, n_k):
+    """Split-precision (3 x bf16) tile kernel vs exact-fp32 MFMA kernel vs the shuffle kernel:
+    three different arithmetic schedules, same q to float32 rounding level."""
     from psa_amd import SEDCalculator, _hip
-    tr = _random_traj(300, 400, seed=9)
+    tr = _random_traj(n_atoms, 400, seed=9)
     calc = SEDCalculator(tr, 1, 1, 1).attach(engine=engine)
-    mags, vecs = calc.get_k_path("xyz", 2.0, 37)
-    a = calc.calculate(mags, vecs).sed
-    engine.set_k1(_hip.K1_WAVE)
+    mags, vecs = calc.get_k_path("xyz", 2.0, n_k)
+    out = {}
     try:
-        b = calc.calculate(mags, vecs).sed
+        for name, sel in (("auto", _hip.K1_AUTO), ("mfma32", _hip.K1_MFMA32), ("wave", _hip.K1_WAVE)):
+            engine.set_k1(sel)
+            out[name] = calc.calculate(mags, vecs).sed
     finally:
         engine.set_k1(_hip.K1_AUTO)
-    assert rel_max(a, b) < 2e-6
+    assert rel_max(out["mfma32"], out["wave"]) < 2e-6
+    assert rel_max(out["auto"], out["mfma32"]) < 2e-6
 
 
 def test_device_intensity_and_chiral_phase(engine, trajs):
