@@ -5,20 +5,28 @@
 // x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)  (round-to-nearest, residuals exact in
 // float32, |x - x1 - x2 - x3| <= 2^-27 |x|), and a product keeps the six leading terms
 //     x*y ~= x1*y1 + x1*y2 + x2*y1 + x2*y2 + x1*y3 + x3*y1        (dropped: <= 2^-26 |x*y|)
-// accumulated in float32 by v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs replace sixteen
+// accumulated in float32 by v_mfma_f32_16x16x32_bf16.  Six bf16 MFMAs replace sixteen
 // float32 MFMA-equivalents: 2.67x the fp32 matrix rate, with one float32 rounding per
-// 16-atom MFMA instead of one per FMA.  (SURVEY.md section 7-2 option (ii); measured
-// accuracy vs the exact-fp32 kernel and the oracle: tests/test_gpu_parity.py.)
+// 32-atom MFMA instead of one per FMA.  (SURVEY.md section 7-2 option (ii); accuracy vs
+// the exact-fp32 kernel and the oracle: tests/test_gpu_parity.py.)
 //
 //  - P' is split ONCE by the phase kernel and stored as three bf16 planes in the tile image
-//    this kernel DMAs into LDS ([piece][M_BLK][32 atoms], 16-byte slots XOR-swizzled by
-//    (row>>2)&3 so that the A-fragment ds_read_b128 are conflict-free).
+//    this kernel DMAs into LDS ([piece][M_BLK][32 atoms], 16-byte slots XOR-swizzled so that
+//    the A-fragment ds_read_b128 are conflict-free).
 //  - d stays float32 in HBM and in LDS (native (T,N,3) rows, same swizzled image as
 //    k1_mfma.hip).  A lane reads its 8 atoms x 3 components = 96 contiguous bytes and splits
-//    them in registers (v_cvt_pk_bf16_f32 / shift / v_pk_add_f32: 4.5 VALU ops per value),
-//    which also resolves the (atom, component) interleave.
-//  - Work decomposition, LDS ring, LDS-DMA, XCD-aware block map and epilogue are those of
-//    k1_mfma.hip; one stage = 32 atoms = two 16-deep MFMA k-steps.
+//    them in registers (v_cvt_pk_bf16_f32 / shift / subtract: ~4.5 VALU ops per value), which
+//    also resolves the (atom, component) interleave.
+//  - Every wavefront owns 32 frames x all M_BLK rows (4 wavefronts side by side along t): a V
+//    element is split once per workgroup, and because a wavefront's V rows are written (by
+//    its own DMA) and read by itself only, the next stage's rows can be read and split BEFORE
+//    the stage barrier, in the shadow of the current MFMAs; only the shared P' tile needs the
+//    barrier.
+//  - MFMA shape: 16x16x32 (one MFMA K = the whole 32-atom stage) rather than 32x32x16: equal
+//    cycles per flop, but the chip holds a higher clock on it (measured here: 26.9 vs 28.3 ms
+//    on configuration 3; MI355X_MICROARCH.md, DVFS give-back item 7).  The kernel is
+//    power/clock-bound: PMC shows the MFMA pipe 73 % busy at ~1.7 GHz.
+//  - LDS ring, LDS-DMA, XCD-aware block map are those of k1_mfma.hip.
 #include <type_traits>
 
 #include "psa_ctx.h"
@@ -112,7 +120,7 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
     const int     tid = threadIdx.x, lane = tid & 63;
     const int     wn = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA
                                                                    // destinations stay in SGPRs
-    const int     l31 = lane & 31, h = lane >> 5;
+    const int     r16 = lane & 15, q = lane >> 4;     // 16x16x32 MFMA: row/col lane, 8-atom group
     const int64_t t0 = (int64_t)tb * C::T_BLK + wn * 32;          // this wavefront's first frame
     const int     n_stage = A_pad / K1_BA;
     const unsigned char* Pt = reinterpret_cast<const unsigned char*>(Pb) +
@@ -134,64 +142,55 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
     }
     const unsigned char* pp = Pt + 16 * (wn * C::P_DMA * 64 + lane);
 
-    f32x16 acc[MT][3];
+    constexpr int MT16 = 2 * MT;                          // 16-row tiles of P'
+    f32x4 acc[MT16][2][3];                                // [row tile][frame tile][component]
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT16; ++mt)
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][c][r] = 0.f;
+            for (int c = 0; c < 3; ++c) acc[mt][tt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int      vrow = wn * 32 + l31;
-    const int      pswz = (l31 >> 2) & 3;
-    const unsigned v_lane = lds0 + vrow * (K1_VROW * 4);                        // this lane's V row
-    const unsigned p_lane = lds0 + 2 * C::V_STAGE_BYTES + l31 * (K1_BA * 2);    // row l31 of plane 0
+    // P' slot swizzle for this shape: slot q of row r is stored at q ^ g((r>>2)&3), g = {0,2,3,1}
+    // (makes the four 16-lane ds_read_b128 groups of the 16x16x32 A fragment conflict-free)
+    const int      gsw = (0x78 >> (2 * ((r16 >> 2) & 3))) & 3;      // g packed two bits each: 0b01_11_10_00 = 0x78
+    const unsigned v_lane = lds0 + (wn * 32 + r16) * (K1_VROW * 4);  // row of frame tile 0
+    const unsigned p_lane = lds0 + 2 * C::V_STAGE_BYTES + r16 * (K1_BA * 2) + ((q ^ gsw) << 4);
 
-    // raw float32 d of k-step KS: atoms 16 KS + 8h .. +7 x 3 components = 96 contiguous bytes in
-    // HBM, six swizzled 16-byte slots in LDS
-    auto read_raw = [&](int buf, int ks, f32x4 (&raw)[6]) {
-        const unsigned base = v_lane + buf * C::V_STAGE_BYTES;
-        const int      s0 = 12 * ks + 6 * h;
-        lds_read128<0>(raw[0], base + 16 * vs_phys_slot(s0 + 0, l31));
-        lds_read128<0>(raw[1], base + 16 * vs_phys_slot(s0 + 1, l31));
-        lds_read128<0>(raw[2], base + 16 * vs_phys_slot(s0 + 2, l31));
-        lds_read128<0>(raw[3], base + 16 * vs_phys_slot(s0 + 3, l31));
-        lds_read128<0>(raw[4], base + 16 * vs_phys_slot(s0 + 4, l31));
-        lds_read128<0>(raw[5], base + 16 * vs_phys_slot(s0 + 5, l31));
+    // raw float32 d of frame tile TT: atoms 8q .. 8q+7 x 3 components = 96 contiguous bytes
+    auto read_raw = [&](int buf, int tt, f32x4 (&raw)[6]) {
+        const unsigned base = v_lane + buf * C::V_STAGE_BYTES + tt * (16 * K1_VROW * 4);
+        const int      s0 = 6 * q;
+        lds_read128<0>(raw[0], base + 16 * vs_phys_slot(s0 + 0, r16));
+        lds_read128<0>(raw[1], base + 16 * vs_phys_slot(s0 + 1, r16));
+        lds_read128<0>(raw[2], base + 16 * vs_phys_slot(s0 + 2, r16));
+        lds_read128<0>(raw[3], base + 16 * vs_phys_slot(s0 + 3, r16));
+        lds_read128<0>(raw[4], base + 16 * vs_phys_slot(s0 + 4, r16));
+        lds_read128<0>(raw[5], base + 16 * vs_phys_slot(s0 + 5, r16));
     };
-    // A fragments of k-step ks: three planes x MT row tiles (plane / tile offsets are immediates)
-    auto read_a = [&](int buf, int ks, bf16x8 (&a)[3][MT]) {
-        const unsigned base = p_lane + buf * C::P_STAGE_BYTES + (((2 * ks + h) ^ pswz) << 4);
-        lds_read128<(0 * C::M_BLK) * 64>(a[0][0], base);
-        lds_read128<(1 * C::M_BLK) * 64>(a[1][0], base);
-        lds_read128<(2 * C::M_BLK) * 64>(a[2][0], base);
-        if constexpr (MT > 1) {
-            lds_read128<(0 * C::M_BLK + 32) * 64>(a[0][1], base);
-            lds_read128<(1 * C::M_BLK + 32) * 64>(a[1][1], base);
-            lds_read128<(2 * C::M_BLK + 32) * 64>(a[2][1], base);
-        }
-        if constexpr (MT > 2) {
-            lds_read128<(0 * C::M_BLK + 64) * 64>(a[0][2], base);
-            lds_read128<(1 * C::M_BLK + 64) * 64>(a[1][2], base);
-            lds_read128<(2 * C::M_BLK + 64) * 64>(a[2][2], base);
-            lds_read128<(0 * C::M_BLK + 96) * 64>(a[0][3], base);
-            lds_read128<(1 * C::M_BLK + 96) * 64>(a[1][3], base);
-            lds_read128<(2 * C::M_BLK + 96) * 64>(a[2][3], base);
-        }
+    // A fragments of the stage (K = 32 atoms): three planes x MT16 row tiles
+    auto read_a = [&](int buf, bf16x8 (&a)[3][MT16]) {
+        const unsigned base = p_lane + buf * C::P_STAGE_BYTES;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int mt = 0; mt < MT16; ++mt)
+                a[p][mt] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(
+                    (const __attribute__((address_space(3))) unsigned char*)(size_t)(base + (p * C::M_BLK + mt * 16) * 64));
     };
     // six products per (row tile, component CC), smallest terms first
-    auto mfma_comp = [&](auto cc, const bf16x8 (&a)[3][MT], const bf16x8 (&bq)[3][3]) {
-        constexpr int c = decltype(cc)::value;
+    auto mfma_comp = [&](auto cc, auto ttc, const bf16x8 (&a)[3][MT16], const bf16x8 (&bq)[3][3]) {
+        constexpr int c = decltype(cc)::value, tt = decltype(ttc)::value;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            f32x16 d = acc[mt][c];
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][mt], bq[0][c], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mt], bq[2][c], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mt], bq[1][c], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mt], bq[0][c], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mt], bq[1][c], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mt], bq[0][c], d, 0, 0, 0);
-            acc[mt][c] = d;
+        for (int mt = 0; mt < MT16; ++mt) {
+            f32x4 d = acc[mt][tt][c];
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2][mt], bq[0][c], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][mt], bq[2][c], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][mt], bq[1][c], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][mt], bq[0][c], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][mt], bq[1][c], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][mt], bq[0][c], d, 0, 0, 0);
+            acc[mt][tt][c] = d;
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -202,7 +201,7 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
     auto interleave = [&](auto valu_c, auto vmem_c) {
         constexpr int valu = decltype(valu_c)::value, vmem = decltype(vmem_c)::value;
 #pragma unroll
-        for (int i = 0; i < 6 * MT; ++i) {
+        for (int i = 0; i < 12 * MT; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             if constexpr (valu > 0) __builtin_amdgcn_sched_group_barrier(0x002, valu, 0);
             if constexpr (vmem > 0)
@@ -257,6 +256,8 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
     //   chunk E: MFMA ks1 c1
     //   chunk F: MFMA ks1 c2 | split ks0 of stage s+1
     //   [barrier]
+    // same pipeline as the 32x32x16 form with "k-step" replaced by "frame tile": one MFMA K
+    // covers the whole 32-atom stage, the wavefront's 32 frames are two 16-column tiles.
     bf16x8 bq0[3][3], bq1[3][3];
     f32x4  raw[6];
 
@@ -266,41 +267,38 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     read_raw(0, 0, raw);
-    lgkm_wait0();
+    __builtin_amdgcn_sched_barrier(0);
     split_component<0>(raw, bq0[0][0], bq0[1][0], bq0[2][0]);
     split_component<1>(raw, bq0[0][1], bq0[1][1], bq0[2][1]);
     split_component<2>(raw, bq0[0][2], bq0[1][2], bq0[2][2]);
 
-    // the body is branch-free (MORE is a compile-time flag, the last stage is peeled): a
-    // conditional DMA or split would open a new basic block and could not be interleaved
     auto stage = [&](auto more_c, int s) {
         constexpr bool more = decltype(more_c)::value;
         const int      buf = s & 1;
-        bf16x8         a0[3][MT], a1[3][MT];
-        read_a(buf, 0, a0);
-        read_a(buf, 1, a1);
+        bf16x8         a[3][MT16];
+        read_a(buf, a);
         read_raw(buf, 1, raw);
         __builtin_amdgcn_sched_barrier(0);
         // chunk A
         if constexpr (more) dma_p(buf ^ 1);
-        mfma_comp(I0{}, a0, bq0);
+        mfma_comp(I0{}, I0{}, a, bq0);
         interleave(N0{}, NP{});
         __builtin_amdgcn_sched_barrier(0);
         // chunk B
         if constexpr (more) dma_v(buf ^ 1, J0{});
         split_component<0>(raw, bq1[0][0], bq1[1][0], bq1[2][0]);
-        mfma_comp(I1{}, a0, bq0);
+        mfma_comp(I1{}, I0{}, a, bq0);
         interleave(V3{}, N6{});
         __builtin_amdgcn_sched_barrier(0);
         // chunk C
         if constexpr (more) dma_v(buf ^ 1, J6{});
         split_component<1>(raw, bq1[0][1], bq1[1][1], bq1[2][1]);
         split_component<2>(raw, bq1[0][2], bq1[1][2], bq1[2][2]);
-        mfma_comp(I2{}, a0, bq0);
+        mfma_comp(I2{}, I0{}, a, bq0);
         interleave(V5{}, N6{});
         __builtin_amdgcn_sched_barrier(0);
         // chunk D
-        mfma_comp(I0{}, a1, bq1);
+        mfma_comp(I0{}, I1{}, a, bq1);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (more) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own DMA of stage s+1 landed
@@ -308,7 +306,7 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
         }
         __builtin_amdgcn_sched_barrier(0);
         // chunk E
-        mfma_comp(I1{}, a1, bq1);
+        mfma_comp(I1{}, I1{}, a, bq1);
         __builtin_amdgcn_sched_barrier(0);
         // chunk F
         if constexpr (more) {
@@ -316,7 +314,7 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
             split_component<1>(raw, bq0[0][1], bq0[1][1], bq0[2][1]);
             split_component<2>(raw, bq0[0][2], bq0[1][2], bq0[2][2]);
         }
-        mfma_comp(I2{}, a1, bq1);
+        mfma_comp(I2{}, I1{}, a, bq1);
         interleave(V5{}, N0{});
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (more) __syncthreads();
@@ -324,20 +322,23 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
     for (int s = 0; s + 1 < n_stage; ++s) stage(std::true_type{}, s);
     stage(std::false_type{}, n_stage - 1);
 
-    const int64_t t = t0 + l31;
-    const int     m0 = mb * C::M_BLK;
-    if (t < T) {
+    // epilogue: accumulator register j of lane (r16, q) is row 4q + j, column r16 of its tile
+    const int m0 = mb * C::M_BLK;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+    for (int tt = 0; tt < 2; ++tt) {
+        const int64_t t = t0 + tt * 16 + r16;
+        if (t < T) {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int r0 = 2 * p;
-                const int i = (r0 & 3) + 8 * (r0 >> 2) + 4 * h;
-                const int k = (m0 + mt * 32 + i) >> 1;
-                if (k < K) {
+            for (int mt = 0; mt < MT16; ++mt) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        Q[((int64_t)k * 3 + c) * T + t] = make_float2(acc[mt][c][r0], acc[mt][c][r0 + 1]);
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int k = (m0 + mt * 16 + 4 * q + 2 * pr) >> 1;
+                    if (k < K) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            Q[((int64_t)k * 3 + c) * T + t] =
+                                make_float2(acc[mt][tt][c][2 * pr], acc[mt][tt][c][2 * pr + 1]);
+                    }
                 }
             }
         }
@@ -351,7 +352,8 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
 __host__ __device__ inline size_t pb_tile_index(int piece, int m, int a, int m_blk, int n_stage) {
     const int    row = m % m_blk, al = a % K1_BA;
     const size_t tile = ((size_t)(m / m_blk) * n_stage + a / K1_BA) * (3 * (size_t)m_blk * K1_BA);
-    return tile + ((size_t)piece * m_blk + row) * K1_BA + ((((al >> 3) ^ ((row >> 2) & 3))) << 3) + (al & 7);
+    const int    sw = (0x78 >> (2 * ((row >> 2) & 3))) & 3;           // g = {0,2,3,1}
+    return tile + ((size_t)piece * m_blk + row) * K1_BA + (((al >> 3) ^ sw) << 3) + (al & 7);
 }
 
 __global__ void __launch_bounds__(256)
