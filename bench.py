@@ -238,6 +238,13 @@ def main():
             out["roofline"]["traffic_source"] = "profiles/r1b_C3_pmc_fetch_write.json (PMC, per launch)"
         if world == 1 and not args.no_cpu_baseline:
             cores = len(os.sched_getaffinity(0))
+            try:                                   # threads the BLAS under NumPy actually runs
+                from threadpoolctl import threadpool_info
+                blas = [i["num_threads"] for i in threadpool_info() if i.get("user_api") == "blas"]
+                if blas:
+                    cores = min(cores, max(blas))
+            except Exception:
+                pass
             n_frames = args.cpu_frames or int(min(T, max(64, 2 ** int(np.log2(1.0e11 / (n_sum_atoms * K))))))
             rate, secs, vel, ref_int, mean_sample = cpu_baseline(spec, tables, r0, types, vecs, kw, n_frames)
             # parity of the HIP path on the very same sample

@@ -98,12 +98,19 @@ class SEDCalculator:
         self._engine = None
 
     def _mean_positions(self) -> np.ndarray:
-        """np.mean(positions, axis=0, dtype=float32) exactly as the reference (:205); cached
-        per positions array because it is a full host pass over (T,N,3)."""
+        """np.mean(positions, axis=0, dtype=float32) exactly as the reference (:205), cached per
+        positions array because it is a full pass over (T,N,3).  In displacement mode the
+        positions have to be in HBM anyway, so the pass runs there (mean_over_frames_kernel adds
+        the frames in the same order into a float32 accumulator: bit-identical); otherwise it
+        is the reference's own NumPy call on the host."""
         pos = self.traj.positions
         if self._mean_cache is not None and self._mean_cache[0]() is pos:
             return self._mean_cache[1]
-        mean = np.mean(pos, axis=0, dtype=np.float32)
+        if self.use_displacements:
+            self.engine.ensure_resident(_hip.SLOT_POSITIONS, pos)
+            mean = self.engine.mean_positions(_hip.SLOT_POSITIONS)
+        else:
+            mean = np.mean(pos, axis=0, dtype=np.float32)
         try:
             self._mean_cache = (weakref.ref(pos), mean)
         except TypeError:

@@ -137,12 +137,6 @@ int run_fft(psa_ctx* c, float2* data, int64_t T, int64_t batch) {
     return PSA_OK;
 }
 
-struct GroupView {
-    const int32_t* host_idx;   // nullptr = identity
-    int64_t        off;        // offset into the uploaded index array
-    int64_t        n;
-};
-
 int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, const int* d_idx, bool disp,
               ProjGeom* g) {
     g->T = c->slot[slot].T;

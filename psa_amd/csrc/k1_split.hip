@@ -77,7 +77,6 @@ __device__ __forceinline__ void lds_read128(T& dst, unsigned addr) {
     dst = *reinterpret_cast<const __attribute__((address_space(3))) T*>(
         (const __attribute__((address_space(3))) unsigned char*)(size_t)(addr + OFF));
 }
-__device__ __forceinline__ void lgkm_wait0() { __builtin_amdgcn_sched_barrier(0); }
 
 // x (two floats) -> three packed bf16 pairs
 __device__ __forceinline__ void split3(f32x2 x, bf16x2& p1, bf16x2& p2, bf16x2& p3) {

@@ -129,6 +129,21 @@ def main():
     out["phase_empty"] = calc.calculate_chiral_phase(z1[:0], z2[:0], "C")
     np.savez_compressed(HERE / "chiral_cases.npz", **out)
 
+    # ---- trajectory .npy cache written by the reference's own loader ------------------------
+    import shutil
+    from psa.io.loader import TrajectoryLoader
+    cache = HERE / "npy_cache"
+    shutil.rmtree(cache, ignore_errors=True)
+    cache.mkdir()
+    (cache / "run7.lammpstrj").write_text("")            # the loader insists the source file exists
+    d = trajs["c"]
+    tr = Trajectory(d["positions"], d["velocities"], d["types"], d["timesteps"],
+                    d["box_matrix"], d["box_lengths"], d["box_tilts"], d["dt_ps"])
+    TrajectoryLoader(str(cache / "run7.lammpstrj"), dt=d["dt_ps"]).save_trajectory_npy(tr)
+    back = TrajectoryLoader(str(cache / "run7.lammpstrj"), dt=d["dt_ps"]).load()
+    np.savez_compressed(HERE / "npy_cache_loaded.npz", timesteps=back.timesteps, box_lengths=back.box_lengths,
+                        box_tilts=back.box_tilts, dt_ps=np.array(back.dt_ps))
+
     (HERE / "META.json").write_text(json.dumps(meta, indent=1) + "\n")
     for f in sorted(HERE.glob("*.npz")):
         print(f"{f.name:24s} {f.stat().st_size/1024:8.1f} KiB")

@@ -24,6 +24,9 @@ class OracleEngine:
     def shape(self, slot):
         return self.slots[slot].shape[:2]
 
+    def mean_positions(self, slot):
+        return O.mean_positions(self.slots[slot])
+
     # hot path
     def project(self, slot, mean_pos_all, k_vectors, groups=None, flags=0, K_total=None, k_offset=0):
         self.calls.append(dict(slot=slot, groups=groups, flags=flags, K=len(k_vectors),

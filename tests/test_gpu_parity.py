@@ -263,3 +263,22 @@ def test_k_offset_slab_rows(engine, trajs):
         engine.project(0, mean, kv, groups, flags)
         whole = engine.finalize(T, 7, bool(flags))
         assert rel_max(parts, whole) < 1e-6
+
+
+def test_memory_mapped_npy_cache_trajectory(engine, trajs):
+    """A trajectory read from the reference's .npy cache (np.memmap arrays) runs as is, in
+    velocity mode and in displacement mode (mean computed on the device, bit-exact)."""
+    from conftest import GOLDEN
+    from psa_amd import SEDCalculator
+    from psa_amd.io import load_trajectory_npy
+    d = trajs["c"]
+    tr = load_trajectory_npy(GOLDEN / "npy_cache" / "run7.lammpstrj", dt=d["dt_ps"])
+    assert isinstance(tr.velocities, np.memmap)
+    for disp in (False, True):
+        calc = SEDCalculator(tr, *d["cells"], use_displacements=disp).attach(engine=engine)
+        mags, vecs = calc.get_k_path("z", 2.0, 5)
+        got = calc.calculate(mags, vecs)
+        ref, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], d["dt_ps"], vecs,
+                                use_displacements=disp)
+        assert rel_max(got.sed, ref) <= TOL
+        np.testing.assert_array_equal(calc._mean_positions(), O.mean_positions(d["positions"]))

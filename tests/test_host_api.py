@@ -291,3 +291,49 @@ def test_composites(trajs):
     assert grid.k_grid_shape == shape == (2, 3) and grid.k_points.size == 0
     np.testing.assert_array_equal(grid.k_vectors, gv)
     assert calc.calculate_chiral_sed("x", 1.0, 3, chiral_axis="z").phase.shape == (128, 3)
+
+
+# ---------------------------------------------------------------- .npy trajectory cache
+def test_npy_cache_written_by_the_reference_loads(trajs):
+    """tests/golden/npy_cache/ was written by the reference's TrajectoryLoader.save_trajectory_npy;
+    npy_cache_loaded.npz holds what its own load() derived from it."""
+    from conftest import GOLDEN
+    from psa_amd.io import load_trajectory_npy
+    d = trajs["c"]
+    for mmap in (True, False):
+        tr = load_trajectory_npy(GOLDEN / "npy_cache" / "run7.lammpstrj", dt=d["dt_ps"], mmap=mmap)
+        np.testing.assert_array_equal(tr.positions, d["positions"])
+        np.testing.assert_array_equal(tr.velocities, d["velocities"])
+        np.testing.assert_array_equal(tr.types, d["types"])
+        np.testing.assert_array_equal(tr.box_matrix, d["box_matrix"])
+        with np.load(GOLDEN / "npy_cache_loaded.npz") as ref:
+            np.testing.assert_array_equal(tr.timesteps, ref["timesteps"])
+            np.testing.assert_array_equal(tr.box_lengths, ref["box_lengths"])
+            np.testing.assert_array_equal(tr.box_tilts, ref["box_tilts"])
+            assert tr.dt_ps == float(ref["dt_ps"])
+    assert isinstance(load_trajectory_npy(GOLDEN / "npy_cache" / "run7", dt=1.0).positions, np.memmap)
+    with pytest.raises(FileNotFoundError):
+        load_trajectory_npy(GOLDEN / "npy_cache" / "other.lammpstrj", dt=1.0)
+
+
+def test_npy_cache_writer_is_byte_compatible(trajs, tmp_path):
+    from conftest import GOLDEN
+    from psa_amd.io import load_trajectory_npy, save_trajectory_npy
+    tr = make_trajectory(trajs["c"])
+    target = tmp_path / "deep" / "run7.lammpstrj"
+    assert save_trajectory_npy(tr, target) is True
+    for ref_file in sorted((GOLDEN / "npy_cache").glob("run7.*.npy")):
+        assert (target.parent / ref_file.name).read_bytes() == ref_file.read_bytes(), ref_file.name
+    assert save_trajectory_npy(tr, target) is False                     # complete cache is left alone
+    back = load_trajectory_npy(target, dt=tr.dt_ps)
+    np.testing.assert_array_equal(back.positions, tr.positions)
+
+
+def test_displacement_mode_takes_the_mean_from_the_device(trajs):
+    d = trajs["a"]
+    eng = OracleEngine()
+    calc = make_calculator(d, use_displacements=True).attach(engine=eng)
+    mean = calc._mean_positions()
+    assert 1 in eng.slots                                             # positions were made resident
+    np.testing.assert_array_equal(mean, O.mean_positions(d["positions"]))
+    assert calc._mean_positions() is mean
