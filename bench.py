@@ -227,15 +227,15 @@ def main():
         if executed:
             out["roofline"]["executed_mfma"] = executed
         out["dtype"] = "f32 (3xbf16 split MFMA, fp32 accumulate)" if split else "f32"
-        # HBM traffic of K1 from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        # in separate runs; FETCH_SIZE doubled for 16-byte/lane streaming reads as
-        # MI355X_MICROARCH.md prescribes) -- only when this run is the profiled workload
-        pmc = ROOT / "profiles" / "r1b_C3_pmc_fetch_write.json"
-        if args.config == "C3" and K == 256 and world == 1 and not intensity_out and pmc.exists() \
-                and args.k1 == "mfma32":
+        # HBM-side traffic of K1 from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs; FETCH_SIZE doubled for 16-byte/lane streaming reads as
+        # MI355X_MICROARCH.md prescribes; counts L2->fabric requests, Infinity-Cache hits included)
+        # -- only when this run is the profiled workload
+        pmc = ROOT / "profiles" / ("r1d_C3_pmc_fetch_write.json" if split else "r1b_C3_pmc_fetch_write.json")
+        if args.config == "C3" and K == 256 and world == 1 and not intensity_out and pmc.exists():
             summ = json.loads(pmc.read_text())["k1_summary"]
             out["roofline"]["traffic"] = summ["fetch_bytes_corrected_x2"] + summ["write_bytes"]
-            out["roofline"]["traffic_source"] = "profiles/r1b_C3_pmc_fetch_write.json (PMC, per launch)"
+            out["roofline"]["traffic_source"] = f"profiles/{pmc.name} (PMC, per launch)"
         if world == 1 and not args.no_cpu_baseline:
             cores = len(os.sched_getaffinity(0))
             try:                                   # threads the BLAS under NumPy actually runs
