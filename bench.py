@@ -30,6 +30,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL needs it on this pool
 
 from psa_amd import _hip, dist, synth                      # noqa: E402
 from psa_amd.core.sed_calculator import SEDCalculator      # noqa: E402
@@ -54,6 +55,9 @@ def parse_args():
     ap.add_argument("--k1", default="auto", choices=["auto", "mfma32"],
                     help="projection kernel: auto = split-precision 3xbf16 MFMA (product default), "
                          "mfma32 = exact-fp32 MFMA")
+    ap.add_argument("--check", action="store_true",
+                    help="after timing, rank 0 recomputes every k-point on its own GPU and compares the "
+                         "gathered result with it (multi-rank plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
@@ -99,6 +103,14 @@ def sum_group_atoms(types, kw):
 
 def main():
     args = parse_args()
+    # The contract is ONE JSON line on stdout.  Gloo and RCCL print banners to fd 1, so the real
+    # stdout is set aside and everything else is routed to stderr.
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    # libpsa_hip (and with it /opt/rocm's HIP runtime, rocFFT, RCCL) is loaded BEFORE torch so that
+    # single- and multi-process runs execute the very same libraries; torch is only used for its
+    # gloo rendezvous below.
+    _hip.load_library()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -214,7 +226,8 @@ def main():
                                    f"{', basis types ' + str(req['basis_atom_types']) if req.get('basis_atom_types') else ''}",
                        "atoms": N, "timesteps": T, "k_points": K, "atom_groups": len(groups),
                        "output": "(T,K) float32 intensity" if intensity_out else "(T,K,3) complex64 + intensity",
-                       "parallelism": f"k-shard x{world} (RCCL gather to rank 0)" if world > 1 else "single GPU",
+                       "parallelism": (f"k-shard x{world} ({'RCCL' if group.transport == 'rccl' else 'HOST-STAGED (RCCL unavailable)'}"
+                                       f" gather to rank 0)") if world > 1 else "single GPU",
                        "device": info["name"]},
             "roofline": {"kernel": kernel_name, "bound": bound,
                          "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
@@ -259,7 +272,13 @@ def main():
                           f"(oracle/psa_oracle.py: NumPy einsum+pocketfft restatement, best of 2, {secs:.1f} s)",
                 "speedup_vs_cpu": units * args.steps / elapsed / rate,
                 "parity_max_rel_intensity_on_sample": err}
-        print(json.dumps(out))
+        if args.check and group.has_result:
+            gathered = engine.result_intensity(T, K) if not intensity_out else engine.finalize(T, K, True)
+            engine.project(_hip.SLOT_VELOCITIES, mean_pos, vecs, dev_groups, flags)
+            alone = engine.finalize(T, K, intensity_out)
+            alone = alone if intensity_out else np.sum(np.abs(alone) ** 2, axis=-1).astype(np.float32)
+            out["shard_check_max_rel"] = float(np.max(np.abs(gathered - alone)) / np.max(np.abs(alone)))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     group.close()
     engine.close()
     if world > 1:

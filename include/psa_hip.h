@@ -133,6 +133,12 @@ int psa_sed_calculate(psa_ctx* ctx, int slot, const float* mean_pos_all,
                       const int32_t* group_idx, const int64_t* group_off, int32_t G,
                       int32_t flags, void* out_host);
 
+/* Raw access to rows [row0, row0+nrows) of the k-major slab (complex64 (nrows,3,T) or float32
+ * (nrows,T), whichever the last psa_sed_project produced): lets a host transport stand in for
+ * psa_sed_gather when no RCCL communicator can be formed, and serves checkpointing. */
+int psa_slab_read(psa_ctx* ctx, int64_t row0, int64_t nrows, void* host);
+int psa_slab_write(psa_ctx* ctx, int64_t row0, int64_t nrows, const void* host);
+
 /* SED.intensity of the finalized complex result, on the device:
  * (T,K) float32 = sum_c |S|^2   (src/psa/core/sed.py:22-24) */
 int psa_result_intensity(psa_ctx* ctx, float* out_host /* (T,K) */);

@@ -52,6 +52,8 @@ SIGNATURES = {
     "psa_sed_finalize": (C.c_int, [_ctx, C.c_void_p]),
     "psa_sed_calculate": (C.c_int, [_ctx, C.c_int, _f32p, _f32p, C.c_int64, _i32p, _i64p,
                                     C.c_int32, C.c_int32, C.c_void_p]),
+    "psa_slab_read": (C.c_int, [_ctx, C.c_int64, C.c_int64, C.c_void_p]),
+    "psa_slab_write": (C.c_int, [_ctx, C.c_int64, C.c_int64, C.c_void_p]),
     "psa_result_intensity": (C.c_int, [_ctx, _f32p]),
     "psa_result_chiral_phase": (C.c_int, [_ctx, C.c_int, C.c_int, _f32p]),
     "psa_last_timings": (C.c_int, [_ctx, C.POINTER(C.c_double)]),
@@ -259,6 +261,16 @@ class Engine:
         T, _ = self.shape(slot)
         self.project(slot, mean_pos_all, k_vectors, groups, flags)
         return self.finalize(T, len(k_vectors), bool(flags & F_INTENSITY))
+
+    def slab_read(self, row0: int, nrows: int, T: int, intensity: bool) -> np.ndarray:
+        out = np.empty((nrows, T), np.float32) if intensity else np.empty((nrows, 3, T), np.complex64)
+        _check(self._lib.psa_slab_read(self._h, row0, nrows, out.ctypes.data_as(C.c_void_p)), "psa_slab_read")
+        return out
+
+    def slab_write(self, row0: int, rows: np.ndarray):
+        rows = np.ascontiguousarray(rows)
+        _check(self._lib.psa_slab_write(self._h, row0, rows.shape[0], rows.ctypes.data_as(C.c_void_p)),
+               "psa_slab_write")
 
     def result_intensity(self, T: int, K: int) -> np.ndarray:
         out = np.empty((T, K), np.float32)

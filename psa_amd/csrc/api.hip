@@ -521,6 +521,47 @@ int psa_sed_calculate(psa_ctx* c, int slot, const float* mean_pos_all, const flo
     return psa_sed_finalize(c, out_host);
 }
 
+static int slab_rows(psa_ctx* c, int64_t row0, int64_t nrows, size_t* off, size_t* bytes) {
+    if (!c->slab_valid) {
+        set_error("no slab: call psa_sed_project first");
+        return PSA_ESTATE;
+    }
+    PSA_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= c->res_K, "slab rows [%lld,%lld) outside [0,%lld)",
+                (long long)row0, (long long)(row0 + nrows), (long long)c->res_K);
+    const size_t row_bytes = c->res_intensity ? (size_t)c->res_T * sizeof(float)
+                                              : (size_t)c->res_T * 3 * sizeof(float2);
+    *off = row_bytes * (size_t)row0;
+    *bytes = row_bytes * (size_t)nrows;
+    return PSA_OK;
+}
+
+int psa_slab_read(psa_ctx* c, int64_t row0, int64_t nrows, void* host) {
+    PSA_TRY(enter(c));
+    Guard guard(c);
+    size_t off = 0, bytes = 0;
+    PSA_TRY(slab_rows(c, row0, nrows, &off, &bytes));
+    PSA_REQUIRE(host != nullptr || bytes == 0, "null host buffer");
+    if (bytes)
+        PSA_HIP_CHECK(hipMemcpyAsync(host, (const char*)c->d_slab.ptr + off, bytes, hipMemcpyDeviceToHost,
+                                     c->stream));
+    PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PSA_OK;
+}
+
+int psa_slab_write(psa_ctx* c, int64_t row0, int64_t nrows, const void* host) {
+    PSA_TRY(enter(c));
+    Guard guard(c);
+    size_t off = 0, bytes = 0;
+    PSA_TRY(slab_rows(c, row0, nrows, &off, &bytes));
+    PSA_REQUIRE(host != nullptr || bytes == 0, "null host buffer");
+    if (bytes)
+        PSA_HIP_CHECK(hipMemcpyAsync((char*)c->d_slab.ptr + off, host, bytes, hipMemcpyHostToDevice,
+                                     c->stream));
+    PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->out_valid = false;
+    return PSA_OK;
+}
+
 int psa_result_intensity(psa_ctx* c, float* out_host) {
     PSA_TRY(enter(c));
     Guard guard(c);

@@ -17,6 +17,7 @@ exports.
 """
 from __future__ import annotations
 
+import logging
 import os
 import pickle
 import socket
@@ -27,6 +28,8 @@ from typing import Any, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _hip
+
+logger = logging.getLogger(__name__)
 
 
 def shard_ranges(n_k: int, nranks: int) -> Tuple[np.ndarray, np.ndarray]:
@@ -186,10 +189,22 @@ class KShardGroup:
         self.rank, self.nranks = exchange.rank, exchange.nranks
         self.gather_mode, self.root = gather, root
         self.has_result = False
+        self.transport = "rccl"
         if self.nranks > 1:
             uid = engine.new_unique_id() if self.rank == 0 else None
             uid = exchange.broadcast(uid, 0)
-            engine.comm_init(uid, self.rank, self.nranks)
+            err = None
+            try:
+                engine.comm_init(uid, self.rank, self.nranks)
+            except _hip.PsaHipError as e:          # e.g. two ranks on one GPU
+                err = str(e)
+            # every rank must take the same path
+            errors = [e for e in exchange.allgather(err) if e]
+            if errors:
+                self.transport = "host"
+                logger.warning("RCCL communicator could not be formed (%s); slab rows will be exchanged "
+                               "through the host rendezvous instead -- correct, but not the xGMI path",
+                               errors[0].splitlines()[-1])
 
     def my_range(self, n_k: int) -> Tuple[int, int]:
         off, cnt = shard_ranges(n_k, self.nranks)
@@ -204,8 +219,22 @@ class KShardGroup:
         self.engine.project(slot, mean_pos_all, np.asarray(k_vectors)[lo:lo + n], groups, flags,
                             K_total=n_k, k_offset=lo)
         if self.nranks > 1:
-            self.engine.gather(-1 if self.gather_mode == "all" else self.root, off, cnt)
+            root = -1 if self.gather_mode == "all" else self.root
+            if self.transport == "rccl":
+                self.engine.gather(root, off, cnt)
+            else:
+                self._host_gather(root, off, cnt, self.engine.shape(slot)[0], bool(flags & _hip.F_INTENSITY))
         self.has_result = self.gather_mode == "all" or self.rank == self.root
+
+    def _host_gather(self, root, off, cnt, T, intensity):
+        """Stand-in for psa_sed_gather when RCCL is unavailable: D2H of this rank's rows, exchange
+        over the host rendezvous, H2D of the others' rows on the receiving rank(s)."""
+        mine = self.engine.slab_read(int(off[self.rank]), int(cnt[self.rank]), T, intensity)
+        parts = self.exchange.allgather(mine)
+        if root < 0 or root == self.rank:
+            for r, rows in enumerate(parts):
+                if r != self.rank and cnt[r] > 0:
+                    self.engine.slab_write(int(off[r]), rows)
 
     def run(self, slot, mean_pos_all, k_vectors, groups, flags, T: int, fetch: bool = True):
         self.project(slot, mean_pos_all, k_vectors, groups, flags)

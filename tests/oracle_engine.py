@@ -70,6 +70,12 @@ class OracleEngine:
                 rows = slice(int(k_offsets[r]), int(k_offsets[r] + k_counts[r]))
                 self._slab[rows] = eng._slab[rows]
 
+    def slab_read(self, row0, nrows, T, intensity):
+        return self._slab[row0:row0 + nrows].copy()
+
+    def slab_write(self, row0, rows):
+        self._slab[row0:row0 + rows.shape[0]] = rows
+
     def finalize(self, T, K, intensity, fetch=True):
         self._out = self._slab.T.copy() if intensity else self._slab.transpose(2, 0, 1).copy()
         return self._out if fetch else None

@@ -35,7 +35,7 @@ def test_shard_ranges_partition(n_k, nranks):
         dist.shard_ranges(4, 0)
 
 
-def _sharded_worker(rank, world, port, backend, gather, results):
+def _sharded_worker(rank, world, port, backend, gather, results, no_rccl=False):
     """One rank of a 2-process k-sharded `calculate` (oracle-backed engine)."""
     import numpy as np
     import conftest
@@ -53,7 +53,14 @@ def _sharded_worker(rank, world, port, backend, gather, results):
 
     class ExchangeEngine(OracleEngine):
         """slab rows travel through the host exchange instead of RCCL"""
+        def comm_init(self, uid, r, n):
+            if no_rccl:                         # what RCCL does for two ranks on one GPU
+                from psa_amd import _hip
+                raise _hip.PsaHipError("psa_comm_init failed (rc=-4): invalid usage")
+            super().comm_init(uid, r, n)
+
         def gather(self, root, k_offsets, k_counts):
+            assert not no_rccl, "RCCL gather used although the communicator could not be formed"
             lo, n = int(k_offsets[self.rank]), int(k_counts[self.rank])
             parts = ex.allgather(self._slab[lo:lo + n])
             if root < 0 or root == self.rank:
@@ -72,6 +79,7 @@ def _sharded_worker(rank, world, port, backend, gather, results):
         sed = calc.calculate(mags, vecs, **kw)
         out[name] = None if sed.sed is None else np.array(sed.sed)
         out[name + "_range"] = (eng.calls[-1]["k_offset"], eng.calls[-1]["K"], eng.calls[-1]["K_total"])
+    out["transport"] = group.transport
     ex.barrier()
     results[rank] = out
     group.close()
@@ -80,15 +88,16 @@ def _sharded_worker(rank, world, port, backend, gather, results):
         td.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend, gather", [("gloo", "all"), ("gloo", "root"), ("tcp", "all")])
-def test_two_rank_sharded_calculate_equals_unsharded(backend, gather):
+@pytest.mark.parametrize("backend, gather, no_rccl", [("gloo", "all", False), ("gloo", "root", False),
+                                                      ("tcp", "all", False), ("gloo", "root", True)])
+def test_two_rank_sharded_calculate_equals_unsharded(backend, gather, no_rccl):
     import conftest
     from oracle import psa_oracle as O
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         results = mgr.dict()
-        procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, backend, gather, results))
+        procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, backend, gather, results, no_rccl))
                  for r in range(world)]
         for p in procs:
             p.start()
@@ -105,6 +114,7 @@ def test_two_rank_sharded_calculate_equals_unsharded(backend, gather):
     ref_i, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], float(d["dt_ps"]), vecs,
                               basis_atom_types=[1, 2], summation_mode="incoherent")
     assert res[0]["coh_range"] == (0, 4, 7) and res[1]["coh_range"] == (4, 3, 7)
+    assert res[0]["transport"] == res[1]["transport"] == ("host" if no_rccl else "rccl")
     for rank in range(world):
         if gather == "root" and rank != 0:
             assert res[rank]["coh"] is None and res[rank]["inc"] is None

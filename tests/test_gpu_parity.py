@@ -282,3 +282,24 @@ def test_memory_mapped_npy_cache_trajectory(engine, trajs):
                                 use_displacements=disp)
         assert rel_max(got.sed, ref) <= TOL
         np.testing.assert_array_equal(calc._mean_positions(), O.mean_positions(d["positions"]))
+
+
+def test_slab_rows_round_trip(engine, trajs):
+    """psa_slab_read / psa_slab_write: the host transport that stands in for the RCCL gather."""
+    d = trajs["a"]
+    mean = O.mean_positions(d["positions"])
+    _, kv = make_calculator(d).get_k_path([1, 1, 0], 2.0, 7)
+    engine.ensure_resident(0, d["velocities"])
+    T = d["velocities"].shape[0]
+    engine.project(0, mean, kv, None, 0)
+    whole = engine.finalize(T, 7, False)
+    rows = engine.slab_read(2, 3, T, False)
+    assert rows.shape == (3, 3, T) and rows.dtype == np.complex64
+    # a second "rank" computes only rows 0-1 and 5-6, the missing rows arrive through the host
+    engine.project(0, mean, kv[:2], None, 0, K_total=7, k_offset=0)
+    engine.project(0, mean, kv[5:], None, 0, K_total=7, k_offset=5)
+    engine.slab_write(2, rows)
+    np.testing.assert_allclose(engine.finalize(T, 7, False), whole, rtol=0, atol=1e-6 * np.abs(whole).max())
+    from psa_amd import _hip
+    with pytest.raises(_hip.PsaHipError):
+        engine.slab_read(5, 3, T, False)
