@@ -53,7 +53,11 @@ template <int MT16>
 struct K1sCfg {
     static constexpr int M_BLK = 16 * MT16;
     static constexpr int T_BLK = 64;                             // 4 wavefronts x 16 frames
-    static constexpr int RING = 3;
+    // M_BLK = 128 fills the register file (1 workgroup/CU): 3-deep ring with the next stage split
+    // in the MFMAs' shadow.  The small-K variants (HBM-bound) fit two workgroups per CU instead:
+    // 2-deep ring each, the other workgroup covers this one's reads, split and barrier.
+    static constexpr int RING = MT16 > 4 ? 3 : 2;
+    static constexpr int WG_PER_CU = MT16 > 4 ? 1 : 2;
     static constexpr int V_STAGE_BYTES = T_BLK * K1_VROW * 4;
     static constexpr int P_STAGE_BYTES = 3 * M_BLK * K1_BA * 2;  // three bf16 planes
     static constexpr int STAGE_BYTES = V_STAGE_BYTES + P_STAGE_BYTES;
@@ -62,7 +66,7 @@ struct K1sCfg {
     static constexpr int P_CHUNKS = P_STAGE_BYTES / 16;
     static constexpr int P_DMA = (P_CHUNKS + 255) / 256;
     static_assert(P_CHUNKS % 64 == 0, "P' tile must be whole wave-instructions");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(WG_PER_CU * LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 __device__ __forceinline__ int vs_phys_slot(int s, int row) { return (s & ~7) | ((s & 7) ^ (row & 7)); }
@@ -108,7 +112,7 @@ __device__ __forceinline__ void split_component(const f32x4 (&raw)[6], bf16x8& b
 
 
 template <int MT16>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256, K1sCfg<MT16>::WG_PER_CU)
 k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
                 float2* __restrict__ Q, int64_t T, int64_t N_tot, int n_g, int A_pad, int K,
                 int n_mblk, int n_tblk) {
@@ -249,71 +253,110 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
     bf16x8 b1[3], b2[3], b3[3];
     f32x4  raw[6];
 
-    // ---- prologue: stages 0 and 1 in flight, stage 0 split ---------------------------------
-    dma_p(0);
-    dma_v(0);
-    if (n_stage > 1) {
-        dma_p(1);
-        dma_v(1);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    read_raw(0, raw);
-    __builtin_amdgcn_sched_barrier(0);
-    split_component<0>(raw, b1[0], b2[0], b3[0]);
-    split_component<1>(raw, b1[1], b2[1], b3[1]);
-    split_component<2>(raw, b1[2], b2[2], b3[2]);
-
-    // One stage.  NEXT: stage s+1 exists (read + split it); NEXT2: stage s+2 exists (DMA it).
-    // Compile-time flags keep the body branch-free so that DMA pieces and split VALU can be
-    // interleaved with the MFMAs of the same basic block.
-    auto stage = [&](auto next_c, auto next2_c, int slot) {
-        constexpr bool next = decltype(next_c)::value, next2 = decltype(next2_c)::value;
-        const int      slot1 = slot == C::RING - 1 ? 0 : slot + 1;
-        const int      slot2 = slot1 == C::RING - 1 ? 0 : slot1 + 1;
-        bf16x8         a[3][MT16];
-        bf16x8         n1[3], n2[3], n3[3];
-        read_a(slot, a);
-        if constexpr (next) read_raw(slot1, raw);
-        __builtin_amdgcn_sched_barrier(0);
-        // chunk 0
-        if constexpr (next2) dma_p(slot2);
-        if constexpr (next) split_component<0>(raw, n1[0], n2[0], n3[0]);
-        mfma_comp(I0{}, a, b1[0], b2[0], b3[0]);
-        interleave(V2{}, NP{});
-        __builtin_amdgcn_sched_barrier(0);
-        // chunk 1
-        if constexpr (next2) dma_v(slot2);
-        if constexpr (next) split_component<1>(raw, n1[1], n2[1], n3[1]);
-        mfma_comp(I1{}, a, b1[1], b2[1], b3[1]);
-        interleave(V2{}, NV{});
-        __builtin_amdgcn_sched_barrier(0);
-        // chunk 2
-        if constexpr (next) split_component<2>(raw, n1[2], n2[2], n3[2]);
-        mfma_comp(I2{}, a, b1[2], b2[2], b3[2]);
-        interleave(V2{}, N0{});
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (next) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                b1[c] = n1[c];
-                b2[c] = n2[c];
-                b3[c] = n3[c];
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stage s+2 landed (own pieces)
-            __syncthreads();                                       // ... everyone's; slot s is free
+    if constexpr (C::RING == 3) {
+        // ---- 3-deep ring: stages 0 and 1 in flight, stage 0 split -----------------------------
+        dma_p(0);
+        dma_v(0);
+        if (n_stage > 1) {
+            dma_p(1);
+            dma_v(1);
         }
-    };
-    int slot = 0;
-    for (int s = 0; s + 2 < n_stage; ++s) {
-        stage(std::true_type{}, std::true_type{}, slot);
-        slot = slot == C::RING - 1 ? 0 : slot + 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        read_raw(0, raw);
+        __builtin_amdgcn_sched_barrier(0);
+        split_component<0>(raw, b1[0], b2[0], b3[0]);
+        split_component<1>(raw, b1[1], b2[1], b3[1]);
+        split_component<2>(raw, b1[2], b2[2], b3[2]);
+
+        // One stage.  NEXT: stage s+1 exists (read + split it); NEXT2: stage s+2 exists (DMA it).
+        // Compile-time flags keep the body branch-free so that DMA pieces and split VALU can be
+        // interleaved with the MFMAs of the same basic block.
+        auto stage = [&](auto next_c, auto next2_c, int slot) {
+            constexpr bool next = decltype(next_c)::value, next2 = decltype(next2_c)::value;
+            const int      slot1 = slot == C::RING - 1 ? 0 : slot + 1;
+            const int      slot2 = slot1 == C::RING - 1 ? 0 : slot1 + 1;
+            bf16x8         a[3][MT16];
+            bf16x8         n1[3], n2[3], n3[3];
+            read_a(slot, a);
+            if constexpr (next) read_raw(slot1, raw);
+            __builtin_amdgcn_sched_barrier(0);
+            // chunk 0
+            if constexpr (next2) dma_p(slot2);
+            if constexpr (next) split_component<0>(raw, n1[0], n2[0], n3[0]);
+            mfma_comp(I0{}, a, b1[0], b2[0], b3[0]);
+            interleave(V2{}, NP{});
+            __builtin_amdgcn_sched_barrier(0);
+            // chunk 1
+            if constexpr (next2) dma_v(slot2);
+            if constexpr (next) split_component<1>(raw, n1[1], n2[1], n3[1]);
+            mfma_comp(I1{}, a, b1[1], b2[1], b3[1]);
+            interleave(V2{}, NV{});
+            __builtin_amdgcn_sched_barrier(0);
+            // chunk 2
+            if constexpr (next) split_component<2>(raw, n1[2], n2[2], n3[2]);
+            mfma_comp(I2{}, a, b1[2], b2[2], b3[2]);
+            interleave(V2{}, N0{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (next) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    b1[c] = n1[c];
+                    b2[c] = n2[c];
+                    b3[c] = n3[c];
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage s+2 landed (own pieces)
+                __syncthreads();                                   // ... everyone's; slot s is free
+            }
+        };
+        int slot = 0;
+        for (int s = 0; s + 2 < n_stage; ++s) {
+            stage(std::true_type{}, std::true_type{}, slot);
+            slot = slot == C::RING - 1 ? 0 : slot + 1;
+        }
+        if (n_stage > 1) {
+            stage(std::true_type{}, std::false_type{}, slot);
+            slot = slot == C::RING - 1 ? 0 : slot + 1;
+        }
+        stage(std::false_type{}, std::false_type{}, slot);
+    } else {
+        // ---- 2-deep ring, two workgroups per CU --------------------------------------------
+        // read this stage | DMA the next one into the other slot | split | MFMA | wait + barrier.
+        // The exposed front of a stage (LDS latency, split, barrier) is covered by the other
+        // workgroup resident on the CU.
+        dma_p(0);
+        dma_v(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        auto stage = [&](auto next_c, int slot) {
+            constexpr bool next = decltype(next_c)::value;
+            bf16x8         a[3][MT16];
+            read_a(slot, a);
+            read_raw(slot, raw);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (next) {
+                dma_p(slot ^ 1);
+                dma_v(slot ^ 1);
+            }
+            split_component<0>(raw, b1[0], b2[0], b3[0]);
+            mfma_comp(I0{}, a, b1[0], b2[0], b3[0]);
+            split_component<1>(raw, b1[1], b2[1], b3[1]);
+            interleave(V2{}, std::integral_constant<int, C::P_DMA + C::V_DMA>{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_comp(I1{}, a, b1[1], b2[1], b3[1]);
+            split_component<2>(raw, b1[2], b2[2], b3[2]);
+            interleave(V2{}, N0{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_comp(I2{}, a, b1[2], b2[2], b3[2]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (next) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        };
+        for (int s = 0; s + 1 < n_stage; ++s) stage(std::true_type{}, s & 1);
+        stage(std::false_type{}, (n_stage - 1) & 1);
     }
-    if (n_stage > 1) {
-        stage(std::true_type{}, std::false_type{}, slot);
-        slot = slot == C::RING - 1 ? 0 : slot + 1;
-    }
-    stage(std::false_type{}, std::false_type{}, slot);
 
     // epilogue: register j of lane (r16, q) is row 4q + j, column r16 of its 16x16 tile; rows
     // 2p, 2p+1 are the cos / sin rows of one k -> one complex64 per lane and register pair
