@@ -201,7 +201,7 @@ def main():
             achieved, peak, unit = flops / (k1_avg_ms * 1e-3) / 1e12, PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
         else:
             achieved, peak, unit = algo_bytes / (k1_avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
-        split = args.k1 == "auto" and dev_groups is None and N % 4 == 0
+        split = args.k1 == "auto"            # every velocity-mode group runs the split kernel
         kernel_name = ("k1_split_kernel (k-projection, 3xbf16 split-precision MFMA, fp32-equivalent)" if split
                        else "k1_mfma_kernel (k-projection, exact-fp32 MFMA)")
         roof_note = ("achieved = algorithmic 12 flop/unit over the kernel time, priced against the fp32 "

@@ -145,8 +145,8 @@ int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, const int* d_i
     g->n_g = (int)n_g;
     g->A_pad = (int)((n_g + 31) / 32 * 32);
     g->K = (int)K_local;
-    // product path: split-precision (3 x bf16) matrix-core kernel whenever the group is the
-    // whole trajectory in order; exact-fp32 MFMA kernel for index lists / displacement mode
+    // product path: split-precision (3 x bf16) matrix-core kernel for every velocity-mode group;
+    // exact-fp32 MFMA kernel for displacement mode
     g->split = c->k1_selector == PSA_K1_AUTO && k1_split_eligible(d_idx, g->N_tot, n_g, disp);
     g->m_blk = g->split ? k1_split_block_rows((int)K_local) : k1_mfma_block_rows((int)K_local);
     g->M_pad = (int)((2 * K_local + g->m_blk - 1) / g->m_blk * g->m_blk);
@@ -175,7 +175,7 @@ int project_group(psa_ctx* c, int slot, const int* d_idx, const ProjGeom& g, boo
         StageTimer st(c, PSA_T_PROJECT);
         const float* d_v = c->slot[slot].buf.as<float>();
         if (split)
-            PSA_TRY(launch_k1_split(c, d_v, c->d_phase.ptr, d_q, g));
+            PSA_TRY(launch_k1_split(c, d_v, c->d_phase.ptr, d_idx, d_q, g));
         else if (c->k1_selector == PSA_K1_WAVE)
             PSA_TRY(launch_k1_wave(c, d_v, c->d_phase.as<float>(), d_idx, c->d_mean_g.as<float>(), d_q,
                                    g, disp));

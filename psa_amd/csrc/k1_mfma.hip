@@ -1,4 +1,7 @@
-// K1 -- the k-projection kernel (the hot kernel of the path).
+// K1, exact-fp32 form -- the k-projection on the fp32 matrix cores.  It serves every atom
+// group the split-precision kernel (k1_split.hip, the default for whole-trajectory groups) does
+// not take: index lists, displacement mode, atom counts that are not a multiple of 4; and any
+// group when PSA_K1_MFMA32 is selected.
 //
 //   q[k, c, t] = sum_a  d[t, a, c] * P[k, a]          d real float32, P complex64
 //

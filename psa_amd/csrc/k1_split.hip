@@ -49,20 +49,28 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
-template <int MT16>
+template <int MT16, bool GATHER>
 struct K1sCfg {
     static constexpr int M_BLK = 16 * MT16;
     static constexpr int T_BLK = 64;                             // 4 wavefronts x 16 frames
-    // M_BLK = 128 fills the register file (1 workgroup/CU): 3-deep ring with the next stage split
-    // in the MFMAs' shadow.  The small-K variants (HBM-bound) fit two workgroups per CU instead:
-    // 2-deep ring each, the other workgroup covers this one's reads, split and barrier.
-    static constexpr int RING = MT16 > 4 ? 3 : 2;
-    static constexpr int WG_PER_CU = MT16 > 4 ? 1 : 2;
-    static constexpr int V_STAGE_BYTES = T_BLK * K1_VROW * 4;
+    // Contiguous groups: M_BLK = 128 fills the register file (1 workgroup/CU) and runs a 3-deep
+    // ring with the next stage split in the MFMAs' shadow; the small-K variants (HBM-bound) fit two
+    // workgroups per CU instead, 2-deep ring each, the other workgroup covering this one's reads,
+    // split and barrier.  Gathered groups have a larger V image (16 bytes per atom): 2-deep ring,
+    // one workgroup per CU.
+    static constexpr int RING = (MT16 > 4 && !GATHER) ? 3 : 2;
+    static constexpr int WG_PER_CU = (MT16 > 4 || GATHER) ? 1 : 2;
+    // V tile of one wavefront: contiguous = 16 rows x 384 B (swizzled 16-byte slots);
+    // gathered = 8 DMA pieces (2 frames x 32 atoms x 16 B, the 12-byte LDS-DMA element lands on a
+    // 16-byte pitch) + 16 B of padding per piece, which keeps the raw reads at 2-way conflicts
+    static constexpr int V_PIECE_BYTES = GATHER ? 1024 + 16 : 1024;
+    static constexpr int V_DMA = GATHER ? 8 : 6;
+    static constexpr int V_WAVE_BYTES = V_DMA * V_PIECE_BYTES;
+    static constexpr int V_STAGE_BYTES = 4 * V_WAVE_BYTES;
     static constexpr int P_STAGE_BYTES = 3 * M_BLK * K1_BA * 2;  // three bf16 planes
     static constexpr int STAGE_BYTES = V_STAGE_BYTES + P_STAGE_BYTES;
     static constexpr int LDS_BYTES = RING * STAGE_BYTES;
-    static constexpr int V_DMA = 6;                              // 16 rows x 24 slots / 64 lanes
+    static constexpr int RAWN = GATHER ? 8 : 6;                  // 16-byte reads per lane per stage
     static constexpr int P_CHUNKS = P_STAGE_BYTES / 16;
     static constexpr int P_DMA = (P_CHUNKS + 255) / 256;
     static_assert(P_CHUNKS % 64 == 0, "P' tile must be whole wave-instructions");
@@ -71,11 +79,10 @@ struct K1sCfg {
 
 __device__ __forceinline__ int vs_phys_slot(int s, int row) { return (s & ~7) | ((s & 7) ^ (row & 7)); }
 
-// hipcc (ROCm 7.2) puts s_waitcnt vmcnt(0) in front of every ds_read it can see while an LDS-DMA is
-// in flight (it cannot prove they do not alias).  The stage schedule below therefore keeps every
-// LDS read outside the window in which the next stage's DMA is in flight: reads at the stage top
-// (previous DMA drained before the barrier) and the early read of the next stage's V rows after
-// the explicit vmcnt(0).
+// One 16-byte LDS read at a byte address (+ compile-time offset).  hipcc (ROCm 7.2) puts
+// s_waitcnt vmcnt(0) in front of every ds_read it can see while an LDS-DMA is in flight (it cannot
+// prove they do not alias); the stage schedules below therefore issue all LDS reads of a stage at
+// its top, before that stage's DMA, when the previous DMA has already been drained.
 template <int OFF, class T>
 __device__ __forceinline__ void lds_read128(T& dst, unsigned addr) {
     dst = *reinterpret_cast<const __attribute__((address_space(3))) T*>(
@@ -95,28 +102,39 @@ __device__ __forceinline__ bf16x8 cat4(bf16x2 a, bf16x2 b, bf16x2 c, bf16x2 d) {
     const bf16x4 hi = __builtin_shufflevector(c, d, 0, 1, 2, 3);
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-// raw = 8 atoms x 3 components, component-minor (24 floats).  Component CC of atoms (2p, 2p+1)
-template <int E>
-__device__ __forceinline__ float relem(const f32x4 (&raw)[6]) { return raw[E >> 2][E & 3]; }
-template <int CC>
-__device__ __forceinline__ void split_component(const f32x4 (&raw)[6], bf16x8& b1, bf16x8& b2, bf16x8& b3) {
+// raw holds a lane's 8 atoms x 3 components: packed (24 floats in 6 register quads, component-
+// minor as in HBM) or padded (one x,y,z,- quad per atom: the gathered image).  Component CC of
+// atom I:
+template <int N, int I, int CC>
+__device__ __forceinline__ float relem(const f32x4 (&raw)[N]) {
+    if constexpr (N == 8) return raw[I][CC];
+    else return raw[(3 * I + CC) >> 2][(3 * I + CC) & 3];
+}
+template <int CC, int N>
+__device__ __forceinline__ void split_component(const f32x4 (&raw)[N], bf16x8& b1, bf16x8& b2, bf16x8& b3) {
     bf16x2 p1[4], p2[4], p3[4];
-    split3(f32x2{relem<0 + CC>(raw), relem<3 + CC>(raw)}, p1[0], p2[0], p3[0]);
-    split3(f32x2{relem<6 + CC>(raw), relem<9 + CC>(raw)}, p1[1], p2[1], p3[1]);
-    split3(f32x2{relem<12 + CC>(raw), relem<15 + CC>(raw)}, p1[2], p2[2], p3[2]);
-    split3(f32x2{relem<18 + CC>(raw), relem<21 + CC>(raw)}, p1[3], p2[3], p3[3]);
+    split3(f32x2{relem<N, 0, CC>(raw), relem<N, 1, CC>(raw)}, p1[0], p2[0], p3[0]);
+    split3(f32x2{relem<N, 2, CC>(raw), relem<N, 3, CC>(raw)}, p1[1], p2[1], p3[1]);
+    split3(f32x2{relem<N, 4, CC>(raw), relem<N, 5, CC>(raw)}, p1[2], p2[2], p3[2]);
+    split3(f32x2{relem<N, 6, CC>(raw), relem<N, 7, CC>(raw)}, p1[3], p2[3], p3[3]);
     b1 = cat4(p1[0], p1[1], p1[2], p1[3]);
     b2 = cat4(p2[0], p2[1], p2[2], p2[3]);
     b3 = cat4(p3[0], p3[1], p3[2], p3[3]);
 }
 
-
-template <int MT16>
-__global__ void __launch_bounds__(256, K1sCfg<MT16>::WG_PER_CU)
-k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
+// GATHER = false: the group is the whole trajectory in order (N % 4 == 0): V rows are copied in
+//                  16-byte pieces into the swizzled image.
+// GATHER = true : arbitrary index list (any order, duplicates) or any N: one (frame, atom) triple
+//                  = one 12-byte LDS-DMA element, 64 atoms per instruction, into a
+//                  [frame][atom][x,y,z,-] image (the hardware places 12-byte elements on a 16-byte
+//                  pitch: tools/probes/dma12.hip).  Each lane serves one atom column of the stage,
+//                  so it needs ONE index per stage.
+template <int MT16, bool GATHER>
+__global__ void __launch_bounds__(256, (K1sCfg<MT16, GATHER>::WG_PER_CU))
+k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb, const int* __restrict__ idx,
                 float2* __restrict__ Q, int64_t T, int64_t N_tot, int n_g, int A_pad, int K,
                 int n_mblk, int n_tblk) {
-    using C = K1sCfg<MT16>;
+    using C = K1sCfg<MT16, GATHER>;
     // ring slot r: [V tile: T_BLK rows x 96 float32][P' tile: 3 planes x M_BLK rows x 32 bf16]
     __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -134,21 +152,42 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
     const int     r16 = lane & 15, q = lane >> 4;                  // frame / row lane, 8-atom group
     const int64_t t0 = (int64_t)tb * C::T_BLK + wn * 16;          // this wavefront's first frame
     const int     n_stage = A_pad / K1_BA;
-    (void)n_g;
 
-    // ---- DMA sources: this wavefront's 16 V rows (6 pieces) + its share of the P' tile -------
-    // One pointer per piece, advanced by one stage (32 atoms = 96 floats) after each issue.  The
-    // last stage of a trajectory whose atom count is not a multiple of 32 reads up to 31 atoms
-    // past the row end: the next frame's data or the zeroed slack behind the array, times P' = 0.
-    const float* vp[C::V_DMA];
+    // ---- DMA sources: this wavefront's 16 V rows + its share of the P' tile -------------------
+    // Contiguous form: one pointer per 1-KiB piece (6), advanced by one stage (32 atoms = 96
+    // floats) after each issue.  The last stage of a trajectory whose atom count is not a multiple
+    // of 32 reads up to 31 atoms past the row end: the next frame's data or the zeroed slack
+    // behind the array, times P' = 0.
+    // Gather form: piece j covers frames 2j, 2j+1 of the wavefront x the stage's 32 atoms; lane l
+    // serves atom column l & 31 of frame 2j + (l >> 5), so it keeps 8 row pointers and one index.
+    constexpr int VP = C::V_DMA;
+    const float*  vp[VP];
 #pragma unroll
-    for (int j = 0; j < C::V_DMA; ++j) {
-        const int L = j * 64 + lane;
-        const int row = L / 24, phys = L - row * 24;
-        int64_t   t = t0 + row;
-        if (t >= T) t = T - 1;                                    // rows past the end: finite filler
-        vp[j] = V + t * 3 * N_tot + 4 * vs_phys_slot(phys, row);
+    for (int j = 0; j < VP; ++j) {
+        if constexpr (GATHER) {
+            int64_t t = t0 + 2 * j + (lane >> 5);
+            if (t >= T) t = T - 1;
+            vp[j] = V + t * 3 * N_tot;
+        } else {
+            const int L = j * 64 + lane;
+            const int row = L / 24, phys = L - row * 24;
+            int64_t   t = t0 + row;
+            if (t >= T) t = T - 1;                                // rows past the end: finite filler
+            vp[j] = V + t * 3 * N_tot + 4 * vs_phys_slot(phys, row);
+        }
     }
+    // atom served by this lane in stage st (columns past the group's end carry P' = 0: any valid atom)
+    auto atom_of = [&](int st) {
+        int pos = st * K1_BA + (lane & 31);
+        if (pos >= n_g) pos = n_g - 1;
+        return idx ? idx[pos] : pos;
+    };
+    int atom_dma = 0, atom_next = 0;        // GATHER: index for the next DMA / the one after
+    if constexpr (GATHER) {
+        atom_dma = atom_of(0);
+        atom_next = atom_of(n_stage > 1 ? 1 : 0);
+    }
+    int dma_count = 0;                      // stages issued so far
     const unsigned char* pp = reinterpret_cast<const unsigned char*>(Pb) +
                               (size_t)mb * n_stage * C::P_STAGE_BYTES + 16 * (wn * C::P_DMA * 64 + lane);
     auto dma_p = [&](int slot) {
@@ -168,11 +207,23 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
         pp += C::P_STAGE_BYTES;
     };
     auto dma_v = [&](int slot) {
-        float* vd = reinterpret_cast<float*>(smem + slot * C::STAGE_BYTES) + wn * 16 * K1_VROW;
+        unsigned char* vd = smem + slot * C::STAGE_BYTES + wn * C::V_WAVE_BYTES;
+        if constexpr (GATHER) {
+            // the index of this stage was loaded a stage ago; fetch the one after next now
+            const int a = atom_dma;
 #pragma unroll
-        for (int j = 0; j < C::V_DMA; ++j) {
-            __builtin_amdgcn_global_load_lds((gbl_void*)vp[j], (lds_void*)(vd + j * 256), 16, 0, 0);
-            vp[j] += K1_VROW;
+            for (int j = 0; j < VP; ++j)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(vp[j] + 3 * (int64_t)a),
+                                                 (lds_void*)(vd + j * C::V_PIECE_BYTES), 12, 0, 0);
+            ++dma_count;
+            atom_dma = atom_next;
+            atom_next = atom_of(dma_count + 1 < n_stage ? dma_count + 1 : n_stage - 1);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VP; ++j) {
+                __builtin_amdgcn_global_load_lds((gbl_void*)vp[j], (lds_void*)(vd + j * C::V_PIECE_BYTES), 16, 0, 0);
+                vp[j] += K1_VROW;
+            }
         }
     };
 
@@ -188,20 +239,34 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
     // P' slot swizzle: slot q of row r is stored at q ^ g((r>>2)&3), g = {0,2,3,1} packed two bits
     // each = 0x78 (makes the four 16-lane ds_read_b128 groups of the A fragment conflict-free)
     const int      gsw = (0x78 >> (2 * ((r16 >> 2) & 3))) & 3;
-    const unsigned v_lane = lds0 + (wn * 16 + r16) * (K1_VROW * 4);
+    // this lane's frame row (gathered: its 8-atom group too) in the wavefront's V tile
+    const unsigned v_lane = lds0 + wn * C::V_WAVE_BYTES +
+                            (GATHER ? (r16 >> 1) * C::V_PIECE_BYTES + (r16 & 1) * 512 + q * 128
+                                    : r16 * (K1_VROW * 4));
     const unsigned p_lane = lds0 + C::V_STAGE_BYTES + r16 * (K1_BA * 2) + ((q ^ gsw) << 4);
 
     // raw float32 d of one stage: atoms 8q .. 8q+7 x 3 components = 96 contiguous bytes in HBM,
     // six swizzled 16-byte slots in LDS
-    auto read_raw = [&](int slot, f32x4 (&raw)[6]) {
+    auto read_raw = [&](int slot, f32x4 (&raw)[C::RAWN]) {
         const unsigned base = v_lane + slot * C::STAGE_BYTES;
-        const int      s0 = 6 * q;
-        lds_read128<0>(raw[0], base + 16 * vs_phys_slot(s0 + 0, r16));
-        lds_read128<0>(raw[1], base + 16 * vs_phys_slot(s0 + 1, r16));
-        lds_read128<0>(raw[2], base + 16 * vs_phys_slot(s0 + 2, r16));
-        lds_read128<0>(raw[3], base + 16 * vs_phys_slot(s0 + 3, r16));
-        lds_read128<0>(raw[4], base + 16 * vs_phys_slot(s0 + 4, r16));
-        lds_read128<0>(raw[5], base + 16 * vs_phys_slot(s0 + 5, r16));
+        if constexpr (GATHER) {                  // 8 atoms x (x,y,z,-): 128 contiguous bytes
+            lds_read128<0>(raw[0], base);
+            lds_read128<16>(raw[1], base);
+            lds_read128<32>(raw[2], base);
+            lds_read128<48>(raw[3], base);
+            lds_read128<64>(raw[4], base);
+            lds_read128<80>(raw[5], base);
+            lds_read128<96>(raw[6], base);
+            lds_read128<112>(raw[7], base);
+        } else {                                 // 96 contiguous bytes of HBM, six swizzled slots
+            const int s0 = 6 * q;
+            lds_read128<0>(raw[0], base + 16 * vs_phys_slot(s0 + 0, r16));
+            lds_read128<0>(raw[1], base + 16 * vs_phys_slot(s0 + 1, r16));
+            lds_read128<0>(raw[2], base + 16 * vs_phys_slot(s0 + 2, r16));
+            lds_read128<0>(raw[3], base + 16 * vs_phys_slot(s0 + 3, r16));
+            lds_read128<0>(raw[4], base + 16 * vs_phys_slot(s0 + 4, r16));
+            lds_read128<0>(raw[5], base + 16 * vs_phys_slot(s0 + 5, r16));
+        }
     };
     // A fragments of the stage (one MFMA K = 32 atoms): three planes x MT16 row tiles
     auto read_a = [&](int slot, bf16x8 (&a)[3][MT16]) {
@@ -246,12 +311,12 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
     };
     using N0 = std::integral_constant<int, 0>;
     using NP = std::integral_constant<int, C::P_DMA>;
-    using NV = std::integral_constant<int, C::V_DMA>;
+    using NV = std::integral_constant<int, VP>;
     using V2 = std::integral_constant<int, 2>;
 
     // split fragments of the CURRENT stage: b[piece][component]
     bf16x8 b1[3], b2[3], b3[3];
-    f32x4  raw[6];
+    f32x4  raw[C::RAWN];
 
     if constexpr (C::RING == 3) {
         // ---- 3-deep ring: stages 0 and 1 in flight, stage 0 split -----------------------------
@@ -341,7 +406,7 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb,
             split_component<0>(raw, b1[0], b2[0], b3[0]);
             mfma_comp(I0{}, a, b1[0], b2[0], b3[0]);
             split_component<1>(raw, b1[1], b2[1], b3[1]);
-            interleave(V2{}, std::integral_constant<int, C::P_DMA + C::V_DMA>{});
+            interleave(V2{}, std::integral_constant<int, C::P_DMA + VP>{});
             __builtin_amdgcn_sched_barrier(0);
             mfma_comp(I1{}, a, b1[1], b2[1], b3[1]);
             split_component<2>(raw, b1[2], b2[2], b3[2]);
@@ -434,21 +499,31 @@ int launch_phase_table_split(psa_ctx* c, const float* d_kvec, const float* d_mea
 }
 
 template <int MT16>
-static int launch_split_variant(psa_ctx* c, const float* d_v, const void* d_phase, float2* d_q,
-                                const ProjGeom& g) {
-    using C = K1sCfg<MT16>;
+static int launch_split_variant(psa_ctx* c, const float* d_v, const void* d_phase, const int* d_idx,
+                                float2* d_q, const ProjGeom& g) {
+    using C = K1sCfg<MT16, false>;
     const int     n_mblk = g.M_pad / C::M_BLK;
     const int64_t n_tblk = (g.T + C::T_BLK - 1) / C::T_BLK;
     const int64_t grid = ((n_tblk + 7) / 8) * 8 * n_mblk;
     PSA_REQUIRE(grid < (1ll << 31) && n_tblk < (1ll << 31), "projection grid too large");
-    hipLaunchKernelGGL((k1_split_kernel<MT16>), dim3((unsigned)grid), dim3(256), 0, c->stream, d_v,
-                       (const __bf16*)d_phase, d_q, g.T, g.N_tot, g.n_g, g.A_pad, g.K, n_mblk, (int)n_tblk);
+    const bool contiguous = d_idx == nullptr && g.N_tot % 4 == 0 && g.n_g == g.N_tot;
+    if (contiguous)
+        hipLaunchKernelGGL((k1_split_kernel<MT16, false>), dim3((unsigned)grid), dim3(256), 0, c->stream, d_v,
+                           (const __bf16*)d_phase, d_idx, d_q, g.T, g.N_tot, g.n_g, g.A_pad, g.K, n_mblk,
+                           (int)n_tblk);
+    else
+        hipLaunchKernelGGL((k1_split_kernel<MT16, true>), dim3((unsigned)grid), dim3(256), 0, c->stream, d_v,
+                           (const __bf16*)d_phase, d_idx, d_q, g.T, g.N_tot, g.n_g, g.A_pad, g.K, n_mblk,
+                           (int)n_tblk);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
 }
 
+// every velocity-mode group; displacement mode (positions - mean while staging) stays on the
+// exact-fp32 kernel's register loader
 bool k1_split_eligible(const int* d_idx, int64_t N_tot, int64_t n_g, bool displacements) {
-    return !displacements && d_idx == nullptr && (N_tot % 4 == 0) && n_g == N_tot;
+    (void)d_idx; (void)N_tot; (void)n_g;
+    return !displacements;
 }
 
 int k1_split_block_rows(int K) {
@@ -458,13 +533,14 @@ int k1_split_block_rows(int K) {
     return 128;
 }
 
-int launch_k1_split(psa_ctx* c, const float* d_v, const void* d_phase, float2* d_q, const ProjGeom& g) {
+int launch_k1_split(psa_ctx* c, const float* d_v, const void* d_phase, const int* d_idx, float2* d_q,
+                    const ProjGeom& g) {
     PSA_REQUIRE(g.A_pad % K1_BA == 0 && g.A_pad >= K1_BA, "A_pad must be a positive multiple of %d", K1_BA);
     PSA_REQUIRE(g.M_pad % g.m_blk == 0, "M_pad not a multiple of the M block");
     switch (g.m_blk) {
-        case 32:  return launch_split_variant<2>(c, d_v, d_phase, d_q, g);
-        case 64:  return launch_split_variant<4>(c, d_v, d_phase, d_q, g);
-        case 128: return launch_split_variant<8>(c, d_v, d_phase, d_q, g);
+        case 32:  return launch_split_variant<2>(c, d_v, d_phase, d_idx, d_q, g);
+        case 64:  return launch_split_variant<4>(c, d_v, d_phase, d_idx, d_q, g);
+        case 128: return launch_split_variant<8>(c, d_v, d_phase, d_idx, d_q, g);
     }
     set_error("no split projection variant for M block %d", g.m_blk);
     return PSA_EINVAL;
