@@ -303,3 +303,14 @@ def test_slab_rows_round_trip(engine, trajs):
     from psa_amd import _hip
     with pytest.raises(_hip.PsaHipError):
         engine.slab_read(5, 3, T, False)
+
+
+@pytest.mark.parametrize("n_atoms, n_frames, n_k", [(1, 1, 1), (3, 2, 2), (5, 1, 40)])
+def test_degenerate_shapes(engine, n_atoms, n_frames, n_k):
+    from psa_amd import SEDCalculator
+    tr = _random_traj(n_atoms, n_frames, seed=1)
+    calc = SEDCalculator(tr, 1, 1, 1).attach(engine=engine)
+    mags, vecs = calc.get_k_path("y", 1.0, n_k)
+    got = calc.calculate(mags, vecs)
+    ref, _, _ = O.calculate(tr.positions, tr.velocities, tr.types, tr.dt_ps, vecs)
+    assert got.sed.shape == (n_frames, n_k, 3) and rel_max(got.sed, ref) <= TOL
