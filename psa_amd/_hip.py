@@ -150,7 +150,10 @@ class Engine:
         _check(self._lib.psa_create(int(device), C.byref(h)), "psa_create")
         self._h = h
         self.device = int(device)
-        self._resident = {}          # slot -> (array id, data pointer, shape)
+        self._resident = {}          # slot -> (weakref to the array, data pointer, shape)
+        # One calculation = upload + project (+ gather) + finalize on ONE context; callers that may
+        # race (the reference GUI computes on worker threads) hold this around the sequence.
+        self.lock = threading.RLock()
         self.rank, self.nranks = 0, 1
 
     # -- lifecycle -------------------------------------------------------------------

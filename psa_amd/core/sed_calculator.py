@@ -136,13 +136,14 @@ class SEDCalculator:
         if intensity:
             flags |= _hip.F_INTENSITY
         eng = self.engine
-        eng.ensure_resident(slot, data)
-        K = len(k_vectors)
-        T = self.traj.n_frames
-        if self._shard is not None and self._shard.nranks > 1:
-            return self._shard.run(slot, mean_pos_all, k_vectors, groups, flags, T, fetch)
-        eng.project(slot, mean_pos_all, k_vectors, groups, flags)
-        return eng.finalize(T, K, intensity, fetch)
+        with eng.lock:                       # project + finalize must not interleave across threads
+            eng.ensure_resident(slot, data)
+            K = len(k_vectors)
+            T = self.traj.n_frames
+            if self._shard is not None and self._shard.nranks > 1:
+                return self._shard.run(slot, mean_pos_all, k_vectors, groups, flags, T, fetch)
+            eng.project(slot, mean_pos_all, k_vectors, groups, flags)
+            return eng.finalize(T, K, intensity, fetch)
 
     # ------------------------------------------------------------------ the seam
     def _calculate_sed_for_group(self, k_vectors_3d: np.ndarray, group_atom_indices: np.ndarray,

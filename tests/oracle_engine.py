@@ -16,6 +16,8 @@ class OracleEngine:
         self.rank, self.nranks = rank, 1
         self._slab = self._meta = self._out = None
         self._peers = peers                      # shared dict rank -> engine (fake "RCCL")
+        import threading
+        self.lock = threading.RLock()
 
     # residency
     def ensure_resident(self, slot, array):

@@ -314,3 +314,29 @@ def test_degenerate_shapes(engine, n_atoms, n_frames, n_k):
     got = calc.calculate(mags, vecs)
     ref, _, _ = O.calculate(tr.positions, tr.velocities, tr.types, tr.dt_ps, vecs)
     assert got.sed.shape == (n_frames, n_k, 3) and rel_max(got.sed, ref) <= TOL
+
+
+def test_calculate_from_worker_threads(engine, trajs):
+    """The reference GUI calculates on daemon threads (psa_gui.py:1015, :2246): concurrent
+    calculations on one context must serialise and both be right."""
+    import threading
+    d = trajs["a"]
+    calcs = [_calc(d, engine) for _ in range(2)]
+    ks = [calcs[0].get_k_path("x", 1.0, 5), calcs[1].get_k_path([1, 1, 0], 2.0, 9)]
+    out, errors = [None, None], []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                out[i] = calcs[i].calculate(*ks[i]).sed
+        except Exception as e:                       # surfaced below
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert not errors, errors
+    for i in range(2):
+        ref, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], d["dt_ps"], ks[i][1])
+        assert out[i].shape == ref.shape and rel_max(out[i], ref) <= TOL
