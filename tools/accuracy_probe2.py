@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Where does the split kernel differ from float64?  (pre-FFT q, per frame)"""
+"""Where do the projection kernels differ from float64?  Pre-FFT q per frame (max, rms, signed
+bias) and, after the FFT, the location of the largest intensity error and dS/S there -- the probe
+that exposed the coherent bias of the single-accumulator split kernel."""
 import sys
 from pathlib import Path
 import numpy as np
