@@ -16,6 +16,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The suite needs libpsa_hip.so (git-ignored build product): build it if it is not there
+    (hipcc cross-compiles gfx950 without a GPU)."""
+    lib = ROOT / "psa_amd" / "csrc" / "libpsa_hip.so"
+    if not lib.exists():
+        import subprocess
+        subprocess.run(["make", "-C", str(lib.parent), "-j", "8"], check=True)
+    yield
+
+
 def rel_max(a, b):
     """max-norm relative error  max|a-b| / max|b|  (SURVEY.md section 8d parity metric)."""
     a, b = np.asarray(a), np.asarray(b)
