@@ -18,11 +18,13 @@ from __future__ import annotations
 
 import logging
 import weakref
+from pathlib import Path
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
 from .. import _hip
+from ..io.writer import out_to_qdump
 from ..utils.helpers import parse_direction
 from .sed import SED
 from .trajectory import Trajectory
@@ -395,3 +397,95 @@ class SEDCalculator:
                              basis_atom_types=basis_atom_types, summation_mode=summation_mode,
                              k_grid_shape=shape, k_chunk_size=k_chunk_size)
         return self._finish(sed, chiral, chiral_axis)
+
+    # ------------------------------------------------------------------ iSED
+    def _ised_groups(self, basis_atom_idx_ised, basis_atom_types_ised) -> List[np.ndarray]:
+        """Atom groups of an iSED reconstruction (reference :389-433): indices win over types; a
+        flat index list is one group, a flat type list is one group PER type."""
+        n_atoms, kinds = self.traj.n_atoms, self.traj.types.astype(int)
+        groups: List[np.ndarray] = []
+        if basis_atom_idx_ised and len(basis_atom_idx_ised) > 0:
+            nested = isinstance(basis_atom_idx_ised[0], list)
+            for members in (basis_atom_idx_ised if nested else [basis_atom_idx_ised]):
+                arr = np.asarray(members, dtype=int)
+                if np.any(arr >= n_atoms) or np.any(arr < 0):
+                    raise ValueError(f"Atom indices in group {members} out of bounds." if nested
+                                     else "Atom indices out of bounds.")
+                if arr.size:
+                    groups.append(arr)
+            if basis_atom_types_ised and len(basis_atom_types_ised) > 0:
+                logger.warning("iSED: atom_indices and atom_types provided. Using atom_indices.")
+        elif basis_atom_types_ised and len(basis_atom_types_ised) > 0:
+            nested = isinstance(basis_atom_types_ised[0], list)
+            for wanted in (basis_atom_types_ised if nested else [[t] for t in basis_atom_types_ised]):
+                members = np.flatnonzero(np.isin(kinds, wanted))
+                if members.size:
+                    groups.append(members)
+                else:
+                    logger.warning("No atoms for type group %s in iSED.", wanted)
+        else:
+            groups.append(np.arange(n_atoms))
+        return groups
+
+    def ised(self, k_dir_spec, k_target: float, w_target: float, char_len_k_path: float,
+             nk_on_path: int = 100, bz_cov_ised: float = 1.0,
+             basis_atom_idx_ised: Optional[List[int]] = None,
+             basis_atom_types_ised: Optional[List[int]] = None,
+             rescale_factor: Union[str, float] = 1.0, n_recon_frames: int = 100,
+             dump_filepath: str = "iSED_reconstruction.dump",
+             plot_dir_ised: Optional[Path] = None, plot_max_freq: Optional[float] = None,
+             plot_theme: str = 'light') -> None:
+        """Inverse SED (reference :373-588): reconstruct the real-space motion of the mode nearest
+        to (k_target, w_target) along a k-path and write it as a LAMMPS dump.  Per atom group the
+        complex SED comes from `calculate` -- on the GPU, against the trajectory already resident
+        in HBM -- and the amplitude A of the selected (w, k) bin is replayed as
+        Re[A exp(i tau - i k r.k_hat)] over one period.  Plotting the input spectrum (the
+        reference's optional last step) is outside this package; `plot_dir_ised` is ignored."""
+        mean_pos = np.mean(self.traj.positions, axis=0, dtype=np.float32)
+        kinds = self.traj.types.astype(int)
+        n_atoms = self.traj.n_atoms
+        k_hat = parse_direction(k_dir_spec)
+        groups = self._ised_groups(basis_atom_idx_ised, basis_atom_types_ised)
+        if not groups:
+            logger.error("iSED: No atom groups for reconstruction. Aborting.")
+            return
+        k_mags, k_vecs = self.get_k_path(direction_spec=k_hat, bz_coverage=bz_cov_ised, n_k=nk_on_path,
+                                         lat_param=char_len_k_path)
+        i_k = int(np.argmin(np.abs(k_mags - k_target)))
+        k_used = k_mags[i_k]
+        tau = np.linspace(0, 2 * np.pi, n_recon_frames, endpoint=False)
+        along_k = np.dot(mean_pos, k_hat)                 # r . k_hat per atom
+        motion = np.zeros((n_recon_frames, n_atoms, 4), dtype=np.float32)   # x, y, z, type
+        auto = isinstance(rescale_factor, str) and rescale_factor.lower() == "auto"
+        peak, spread_sum, spread_atoms = 0.0, 0.0, 0
+
+        for members in groups:
+            sed = self.calculate(k_points_mags=k_mags, k_vectors_3d=k_vecs, basis_atom_indices=members,
+                                 k_grid_shape=None, summation_mode='coherent')
+            i_w = int(np.argmin(np.abs(sed.freqs - w_target)))
+            carrier = np.exp(1j * tau[:, None] - 1j * k_used * along_k[members][None, :])
+            for axis in range(3):
+                motion[:, members, axis] += np.real(sed.sed[i_w, i_k, axis] * carrier)
+            if auto:
+                peak = max(peak, float(np.amax(np.abs(motion[:, members, :3]))))
+                thermal = self.traj.positions[:, members, :] - mean_pos[None, members, :]
+                spread_sum += np.std(thermal) * len(members)
+                spread_atoms += len(members)
+
+        motion[0, :, 3] = kinds
+        touched = np.unique(np.concatenate(groups))
+        if auto:
+            if peak > 1e-9:
+                motion[:, touched, :3] /= peak
+                typical = spread_sum / spread_atoms if spread_atoms > 0 else 0.0
+                if typical > 1e-9:
+                    motion[:, touched, :3] *= typical
+            else:
+                logger.warning("iSED: Max wiggle amp near zero. Auto-rescaling ineffective.")
+        elif isinstance(rescale_factor, (int, float)):
+            motion[:, touched, :3] *= rescale_factor
+        out_to_qdump(dump_filepath, mean_pos[None, :, :] + motion[:, :, :3], motion[0, :, 3].astype(int),
+                     self.traj.box_matrix)
+        logger.info("iSED reconstruction saved: %s", dump_filepath)
+        if plot_dir_ised:
+            logger.warning("iSED: plotting the input spectrum is not part of psa_amd; plot_dir_ised ignored.")

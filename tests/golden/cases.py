@@ -141,3 +141,24 @@ def k_from_spec(calc, spec):
         return mags, vecs, None
     _, plane, rx, ry, nkx, nky, fixed = spec
     return calc.get_k_grid(plane, rx, ry, nkx, nky, fixed)
+
+
+# iSED reconstructions: (name, trajectory, keyword arguments of SEDCalculator.ised)
+ISED_CASES = [
+    ("all_atoms", "a", dict(k_dir_spec="x", k_target=0.58, w_target=19.5, char_len_k_path=A_SI,
+                            nk_on_path=8, bz_cov_ised=1.0, n_recon_frames=6)),
+    ("per_type_auto", "a", dict(k_dir_spec=[1, 1, 0], k_target=0.4, w_target=30.0, char_len_k_path=A_SI,
+                                nk_on_path=5, bz_cov_ised=2.0, basis_atom_types_ised=[1, 2, 3],
+                                rescale_factor="auto", n_recon_frames=4)),
+    ("index_groups_triclinic", "b", dict(k_dir_spec="x", k_target=0.2, w_target=70.0, char_len_k_path=2.0,
+                                         nk_on_path=6, basis_atom_idx_ised=[[0, 1, 2, 40], [5, 6]],
+                                         rescale_factor=2.5, n_recon_frames=3)),
+]
+
+
+def qdump_tilted_inputs():
+    """(positions (2,5,3), types, box matrix with upper-triangle tilts) for the dump writer alone."""
+    rng = np.random.default_rng(5)
+    pos = (10 * rng.standard_normal((2, 5, 3))).astype(np.float32)
+    box = np.array([[12.0, 1.5, -0.75], [0.0, 9.0, -2.25], [0.0, 0.0, 7.5]], np.float32)
+    return pos, np.array([1, 2, 2, 3, 1]), box

@@ -144,6 +144,15 @@ def main():
     np.savez_compressed(HERE / "npy_cache_loaded.npz", timesteps=back.timesteps, box_lengths=back.box_lengths,
                         box_tilts=back.box_tilts, dt_ps=np.array(back.dt_ps))
 
+    # ---- iSED: the reference's reconstruction dumps (text) for three parameter sets ---------------
+    ised_dir = HERE / "ised"
+    shutil.rmtree(ised_dir, ignore_errors=True)
+    ised_dir.mkdir()
+    for name, tname, kw in C.ISED_CASES:
+        make_calc(tname).ised(dump_filepath=str(ised_dir / f"{name}.dump"), **kw)
+    from psa.io.writer import out_to_qdump               # the writer alone, tilted cell
+    out_to_qdump(str(ised_dir / "writer_tilted.dump"), *C.qdump_tilted_inputs())
+
     (HERE / "META.json").write_text(json.dumps(meta, indent=1) + "\n")
     for f in sorted(HERE.glob("*.npz")):
         print(f"{f.name:24s} {f.stat().st_size/1024:8.1f} KiB")
