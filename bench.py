@@ -38,7 +38,7 @@ from psa_amd.core.trajectory import Trajectory             # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md:41-42 (dense, v_mfma_f32_32x32x2_f32)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # ibid. :43 (dense bf16 MFMA)
-SPLIT_MFMA_FLOP_PER_UNIT = 72     # 6 bf16 products per fp32 product in the 3xbf16 split kernel
+SPLIT_MFMA_FLOP_PER_UNIT = {"auto": 36, "bf16x3": 72}   # 16-bit products issued per fp32 product: 3 (2xf16) / 6 (3xbf16)
 PEAK_HBM_GBS = 8000.0             # ibid. :36 (spec; 6.29 TB/s measured copy)
 FLOP_PER_UNIT = 12                # 3 components x (re, im) x FMA per (k, t, atom)  
 
@@ -52,9 +52,9 @@ def parse_args():
     ap.add_argument("--summation", default="coherent", choices=["coherent", "incoherent"])
     ap.add_argument("--k-points", type=int, default=0,
                     help="override the config's k-point count (diagnostics, e.g. 32 = one rank's shard of C3 on 8 GPUs)")
-    ap.add_argument("--k1", default="auto", choices=["auto", "mfma32"],
-                    help="projection kernel: auto = split-precision 3xbf16 MFMA (product default), "
-                         "mfma32 = exact-fp32 MFMA")
+    ap.add_argument("--k1", default="auto", choices=["auto", "bf16x3", "mfma32"],
+                    help="projection kernel: auto = split-precision 2xf16 MFMA (product default), "
+                         "bf16x3 = split-precision 3xbf16 MFMA, mfma32 = exact-fp32 MFMA")
     ap.add_argument("--check", action="store_true",
                     help="after timing, rank 0 recomputes every k-point on its own GPU and compares the "
                          "gathered result with it (multi-rank plumbing check)")
@@ -136,7 +136,7 @@ def main():
 
     engine = _hip.Engine(local_rank % max(1, _hip.device_count()))
     info = engine.device_info()
-    engine.set_k1(_hip.K1_MFMA32 if args.k1 == "mfma32" else _hip.K1_AUTO)
+    engine.set_k1({"auto": _hip.K1_AUTO, "bf16x3": _hip.K1_SPLIT_BF16, "mfma32": _hip.K1_MFMA32}[args.k1])
     synth.fill_device(engine, _hip.SLOT_VELOCITIES, spec, tables)     # V generated in HBM
     group = dist.KShardGroup(engine, exchange, gather="root", root=0)
 
@@ -201,15 +201,17 @@ def main():
             achieved, peak, unit = flops / (k1_avg_ms * 1e-3) / 1e12, PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
         else:
             achieved, peak, unit = algo_bytes / (k1_avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
-        split = args.k1 == "auto"            # every velocity-mode group runs the split kernel
-        kernel_name = ("k1_split_kernel (k-projection, 3xbf16 split-precision MFMA, fp32-equivalent)" if split
+        split = args.k1 != "mfma32"          # every velocity-mode group runs the split kernel
+        split_name = {"auto": "2xf16", "bf16x3": "3xbf16", "mfma32": ""}[args.k1]
+        kernel_name = (f"k1_split_kernel (k-projection, {split_name} split-precision MFMA, fp32-equivalent)" if split
                        else "k1_mfma_kernel (k-projection, exact-fp32 MFMA)")
         roof_note = ("achieved = algorithmic 12 flop/unit over the kernel time, priced against the fp32 "
                      "matrix-core peak (the precision the path delivers); frac > 1 is the split-precision gain")
         executed = None
         if split:
-            ex_rate = SPLIT_MFMA_FLOP_PER_UNIT * per_launch_units / (k1_avg_ms * 1e-3) / 1e12
-            executed = {"what": "bf16 MFMA flop actually issued (6 products per fp32 product)",
+            ex_rate = SPLIT_MFMA_FLOP_PER_UNIT[args.k1] * per_launch_units / (k1_avg_ms * 1e-3) / 1e12
+            executed = {"what": f"16-bit MFMA flop actually issued ({SPLIT_MFMA_FLOP_PER_UNIT[args.k1] // 12} "
+                                f"products per fp32 product)",
                         "rate": ex_rate, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": ex_rate / PEAK_BF16_MFMA_TFLOPS}
         out = {
@@ -239,12 +241,13 @@ def main():
         }
         if executed:
             out["roofline"]["executed_mfma"] = executed
-        out["dtype"] = "f32 (3xbf16 split MFMA, fp32 accumulate)" if split else "f32"
+        out["dtype"] = f"f32 ({split_name} split MFMA, fp32 accumulate)" if split else "f32"
         # HBM-side traffic of K1 from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs; FETCH_SIZE doubled for 16-byte/lane streaming reads as
         # MI355X_MICROARCH.md prescribes; counts L2->fabric requests, Infinity-Cache hits included)
         # -- only when this run is the profiled workload
-        pmc = ROOT / "profiles" / ("r1d_C3_pmc_fetch_write.json" if split else "r1b_C3_pmc_fetch_write.json")
+        pmc = ROOT / "profiles" / {"auto": "r1g_C3_pmc_fetch_write.json", "bf16x3": "r1d_C3_pmc_fetch_write.json",
+                                   "mfma32": "r1b_C3_pmc_fetch_write.json"}[args.k1]
         if args.config == "C3" and K == 256 and world == 1 and not intensity_out and pmc.exists():
             summ = json.loads(pmc.read_text())["k1_summary"]
             out["roofline"]["traffic"] = summ["fetch_bytes_corrected_x2"] + summ["write_bytes"]

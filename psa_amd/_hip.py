@@ -20,7 +20,7 @@ LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libpsa_hip.so"
 
 SLOT_VELOCITIES, SLOT_POSITIONS = 0, 1
 F_DISPLACEMENTS, F_INTENSITY = 0x1, 0x2
-K1_AUTO, K1_WAVE, K1_MFMA32 = 0, 1, 2
+K1_AUTO, K1_WAVE, K1_MFMA32, K1_SPLIT_BF16 = 0, 1, 2, 3
 UNIQUE_ID_BYTES = 128
 TIMING_NAMES = ("h2d", "phase", "project", "fft", "epilogue", "gather", "transpose", "d2h")
 

@@ -137,6 +137,19 @@ int run_fft(psa_ctx* c, float2* data, int64_t T, int64_t batch) {
     return PSA_OK;
 }
 
+// largest magnitude of a resident array: one HBM pass + a 4-byte read-back, once per upload
+int slot_absmax(psa_ctx* c, int slot) {
+    DataSlot& s = c->slot[slot];
+    if (s.absmax_known) return PSA_OK;
+    PSA_TRY(c->d_absmax.reserve(sizeof(unsigned)));
+    PSA_TRY(launch_absmax_bits(c, s.buf.as<float>(), s.T * s.N * 3, c->d_absmax.as<unsigned>()));
+    PSA_HIP_CHECK(hipMemcpyAsync(&s.absmax_bits, c->d_absmax.ptr, sizeof(unsigned), hipMemcpyDeviceToHost,
+                                 c->stream));
+    PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    s.absmax_known = true;
+    return PSA_OK;
+}
+
 int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, const int* d_idx, bool disp,
               ProjGeom* g) {
     g->T = c->slot[slot].T;
@@ -145,22 +158,40 @@ int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, const int* d_i
     g->n_g = (int)n_g;
     g->A_pad = (int)((n_g + 31) / 32 * 32);
     g->K = (int)K_local;
-    // product path: split-precision (3 x bf16) matrix-core kernel for every velocity-mode group;
-    // exact-fp32 MFMA kernel for displacement mode
-    g->split = c->k1_selector == PSA_K1_AUTO && k1_split_eligible(d_idx, g->N_tot, n_g, disp);
-    g->m_blk = g->split ? k1_split_block_rows((int)K_local) : k1_mfma_block_rows((int)K_local);
+    // product path: split-precision matrix-core kernels for velocity data -- "2 x f16" for whole-
+    // trajectory groups with 2K > 64 (unless the array holds NaN/Inf), "3 x bf16" for every other
+    // group; exact-fp32 MFMA kernel for displacement mode
+    g->split = 0;
+    const bool autosel = c->k1_selector == PSA_K1_AUTO;
+    if (autosel && k1_direct_eligible(d_idx, g->N_tot, n_g, K_local, disp)) {
+        PSA_TRY(slot_absmax(c, slot));
+        g->vscale = k1_f16_vscale(c->slot[slot].absmax_bits);
+        if (g->vscale > 0.f) g->split = 2;
+    }
+    if (g->split == 0 && (autosel || c->k1_selector == PSA_K1_SPLIT_BF16) &&
+        k1_split_eligible(d_idx, g->N_tot, n_g, disp))
+        g->split = 3;
+    if (g->split == 2) {
+        g->m_blk = 128;
+        g->A_pad = k1_direct_atom_pad(n_g);
+    } else {
+        g->m_blk = g->split ? k1_split_block_rows((int)K_local) : k1_mfma_block_rows((int)K_local);
+    }
     g->M_pad = (int)((2 * K_local + g->m_blk - 1) / g->m_blk * g->m_blk);
     return PSA_OK;
 }
 
 // phase table + projection of one group into q (K_local,3,T); no FFT
 int project_group(psa_ctx* c, int slot, const int* d_idx, const ProjGeom& g, bool disp, float2* d_q) {
-    const bool split = g.split;
-    PSA_TRY(c->d_phase.reserve(split ? pb_table_bytes(g.M_pad, g.A_pad)
-                                     : p_table_floats(g.M_pad, g.A_pad) * sizeof(float)));
+    const bool split = g.split == 3;
+    PSA_TRY(c->d_phase.reserve(g.split == 2 ? pf16_table_bytes(g.M_pad, g.A_pad)
+                               : split     ? pb_table_bytes(g.M_pad, g.A_pad)
+                                           : p_table_floats(g.M_pad, g.A_pad) * sizeof(float)));
     {
         StageTimer st(c, PSA_T_PHASE);
-        if (split)
+        if (g.split == 2)
+            PSA_TRY(launch_phase_table_f16(c, c->d_kvec.as<float>(), c->d_mean_all.as<float>(), c->d_phase.ptr, g));
+        else if (split)
             PSA_TRY(launch_phase_table_split(c, c->d_kvec.as<float>(), c->d_mean_all.as<float>(), d_idx,
                                              c->d_phase.ptr, g));
         else
@@ -174,7 +205,9 @@ int project_group(psa_ctx* c, int slot, const int* d_idx, const ProjGeom& g, boo
     {
         StageTimer st(c, PSA_T_PROJECT);
         const float* d_v = c->slot[slot].buf.as<float>();
-        if (split)
+        if (g.split == 2)
+            PSA_TRY(launch_k1_direct(c, d_v, c->d_phase.ptr, d_q, g));
+        else if (split)
             PSA_TRY(launch_k1_split(c, d_v, c->d_phase.ptr, d_idx, d_q, g));
         else if (c->k1_selector == PSA_K1_WAVE)
             PSA_TRY(launch_k1_wave(c, d_v, c->d_phase.as<float>(), d_idx, c->d_mean_g.as<float>(), d_q,
@@ -268,7 +301,7 @@ int psa_destroy(psa_ctx* c) {
         for (auto ev : c->timing.pool) (void)hipEventDestroy(ev);
         for (auto& s : c->slot) s.buf.release();
         for (DevBuf* b : {&c->d_kvec, &c->d_mean_all, &c->d_idx, &c->d_mean_g, &c->d_phase, &c->d_qwork,
-                          &c->d_fft_work, &c->d_tables, &c->d_slab, &c->d_out, &c->d_aux, &c->d_sync})
+                          &c->d_fft_work, &c->d_tables, &c->d_absmax, &c->d_slab, &c->d_out, &c->d_aux, &c->d_sync})
             b->release();
         (void)hipStreamDestroy(c->stream);
     }
@@ -285,7 +318,8 @@ int psa_synchronize(psa_ctx* c) {
 
 int psa_set_k1(psa_ctx* c, int selector) {
     PSA_TRY(enter(c));
-    PSA_REQUIRE(selector == PSA_K1_AUTO || selector == PSA_K1_WAVE || selector == PSA_K1_MFMA32,
+    PSA_REQUIRE(selector == PSA_K1_AUTO || selector == PSA_K1_WAVE || selector == PSA_K1_MFMA32 ||
+                    selector == PSA_K1_SPLIT_BF16,
                 "unknown K1 selector %d", selector);
     Guard g(c);
     c->k1_selector = selector;
@@ -314,11 +348,13 @@ int psa_data_alloc(psa_ctx* c, int slot, int64_t T, int64_t N) {
     PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
     DataSlot& s = c->slot[slot];
     s.valid = false;
-    // 512 zeroed bytes behind the array: the split projection kernel's last atom stage may read
-    // up to 31 atoms past the final row (multiplied by a zero phase column)
+    s.absmax_known = false;
+    // 4 KiB of zeros behind the array: the split projection kernels pad the atom axis (to 32, or
+    // 256 atoms in k1_direct.hip) and read up to 255 atoms past the final row, multiplied by zero
+    // phase columns
     const size_t bytes = (size_t)T * N * 3 * sizeof(float);
-    PSA_TRY(s.buf.reserve(bytes + 512));
-    PSA_HIP_CHECK(hipMemsetAsync((char*)s.buf.ptr + bytes, 0, 512, c->stream));
+    PSA_TRY(s.buf.reserve(bytes + 4096));
+    PSA_HIP_CHECK(hipMemsetAsync((char*)s.buf.ptr + bytes, 0, 4096, c->stream));
     s.T = T;
     s.N = N;
     s.valid = true;
@@ -386,6 +422,7 @@ int psa_data_fill_synthetic(psa_ctx* c, int slot, uint64_t seed, int n_modes, co
     if (n_modes > 0)
         PSA_REQUIRE(amp && mode_comp && ct && st && ca && sa, "null mode table");
     const int64_t T = c->slot[slot].T, N = c->slot[slot].N;
+    c->slot[slot].absmax_known = false;
     // one packed upload: amp | comp | ct | st | ca | sa
     const size_t nm = (size_t)n_modes;
     const size_t o_amp = 0, o_comp = o_amp + nm * 4, o_ct = o_comp + nm * 4, o_st = o_ct + nm * T * 4,

@@ -155,4 +155,38 @@ int launch_mean_over_frames(psa_ctx* c, const float* d_x, int64_t T, int64_t N, 
     return PSA_OK;
 }
 
+// ---------------------------------------------------------------------------
+// largest |x| of a resident array, as float bits (non-negative floats order like unsigned
+// integers; a NaN or Inf anywhere makes the result >= 0x7f800000).  The split-precision
+// projection kernel derives from it the power of two that places the data at the top of the
+// float16 range.  One pass at HBM rate, run once per upload.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+absmax_bits_kernel(const float4* __restrict__ x4, int64_t n4, const float* __restrict__ tail, int n_tail,
+                   unsigned* __restrict__ out) {
+    unsigned m = 0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 v = x4[i];
+        m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+        m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) m = max(m, __float_as_uint(tail[threadIdx.x]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+int launch_absmax_bits(psa_ctx* c, const float* d_x, int64_t n, unsigned* d_out) {
+    PSA_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(unsigned), c->stream));
+    const int64_t n4 = n / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream,
+                       reinterpret_cast<const float4*>(d_x), n4, d_x + 4 * n4, (int)(n - 4 * n4), d_out);
+    PSA_HIP_CHECK(hipGetLastError());
+    return PSA_OK;
+}
+
 }  // namespace psa

@@ -83,6 +83,9 @@ struct DataSlot {
     DevBuf  buf;
     int64_t T = 0, N = 0;
     bool    valid = false;
+    // largest |x| of the array (float bits), computed on first use after the contents change
+    bool     absmax_known = false;
+    unsigned absmax_bits = 0;
 };
 
 // stage timing: event pairs recorded on the context's stream, resolved lazily
@@ -119,7 +122,8 @@ struct ProjGeom {
     int     K = 0;        // k-vectors (rows of the output)
     int     M_pad = 0;    // 2K rounded up to the variant's M block
     int     m_blk = 0;    // rows of P per workgroup (variant)
-    bool    split = false;  // split-precision (3 x bf16) kernel + bf16-plane phase table
+    int     split = 0;    // 0: float32 kernels; 2: "2 x f16" kernel (k1_direct.hip); 3: "3 x bf16" (k1_split.hip)
+    float   vscale = 0.f; // split == 2: power of two applied to d (from the slot's largest magnitude)
 };
 
 }  // namespace psa
@@ -137,7 +141,7 @@ struct psa_ctx {
     psa::DataSlot slot[PSA_NUM_SLOTS];
 
     // per-call scratch
-    psa::DevBuf d_kvec, d_mean_all, d_idx, d_mean_g, d_phase, d_qwork, d_fft_work, d_tables;
+    psa::DevBuf d_kvec, d_mean_all, d_idx, d_mean_g, d_phase, d_qwork, d_fft_work, d_tables, d_absmax;
     // results
     psa::DevBuf d_slab;      // k-major: (K_total,3,T) c64  or (K_total,T) f32
     psa::DevBuf d_out;       // reference layout: (T,K_total,3) c64 or (T,K_total) f32
@@ -166,6 +170,7 @@ int launch_fill_synthetic(psa_ctx* c, float* d_v, int64_t T, int64_t N, uint64_t
                           const float* d_amp, const int* d_comp, const float* d_ct,
                           const float* d_st, const float* d_ca, const float* d_sa);
 int launch_mean_over_frames(psa_ctx* c, const float* d_x, int64_t T, int64_t N, float* d_mean);
+int launch_absmax_bits(psa_ctx* c, const float* d_x, int64_t n, unsigned* d_out);
 
 // --- k1_mfma.hip / k1_wave.hip
 int  k1_mfma_block_rows(int K);                    // M block of the variant chosen for K
@@ -174,7 +179,7 @@ int  launch_k1_mfma(psa_ctx* c, const float* d_v, const float* d_phase, const in
 int  launch_k1_wave(psa_ctx* c, const float* d_v, const float* d_phase, const int* d_idx,
                     const float* d_mean_g, float2* d_q, const ProjGeom& g, bool displacements);
 
-// --- k1_split.hip
+// --- k1_split.hip ("3 x bf16": any velocity-mode group)
 bool   k1_split_eligible(const int* d_idx, int64_t N_tot, int64_t n_g, bool displacements);
 int    k1_split_block_rows(int K);
 size_t pb_table_bytes(int M_pad, int A_pad);
@@ -182,6 +187,15 @@ int    launch_phase_table_split(psa_ctx* c, const float* d_kvec, const float* d_
                                 void* d_phase, const ProjGeom& g);
 int    launch_k1_split(psa_ctx* c, const float* d_v, const void* d_phase, const int* d_idx, float2* d_q,
                        const ProjGeom& g);
+
+// --- k1_direct.hip ("2 x f16": whole-trajectory groups, 2K > 64)
+bool   k1_direct_eligible(const int* d_idx, int64_t N_tot, int64_t n_g, int64_t K, bool displacements);
+int    k1_direct_atom_pad(int64_t n_g);
+float  k1_f16_vscale(unsigned absmax_bits);
+size_t pf16_table_bytes(int M_pad, int A_pad);
+int    launch_phase_table_f16(psa_ctx* c, const float* d_kvec, const float* d_mean_all, void* d_phase,
+                              const ProjGeom& g);
+int    launch_k1_direct(psa_ctx* c, const float* d_v, const void* d_phase, float2* d_q, const ProjGeom& g);
 
 // --- k2_epilogue.hip
 int launch_scale_transpose_c64(psa_ctx* c, const float2* d_slab, float2* d_out, int64_t T, int64_t K);

@@ -42,8 +42,8 @@ def test_constants_match_header():
         return int(re.search(rf"#define\s+{name}\s+(-?\w+)", HEADER).group(1), 0)
     assert (_hip.SLOT_VELOCITIES, _hip.SLOT_POSITIONS) == (const("PSA_SLOT_VELOCITIES"), const("PSA_SLOT_POSITIONS"))
     assert (_hip.F_DISPLACEMENTS, _hip.F_INTENSITY) == (const("PSA_F_DISPLACEMENTS"), const("PSA_F_INTENSITY"))
-    assert (_hip.K1_AUTO, _hip.K1_WAVE, _hip.K1_MFMA32) == (const("PSA_K1_AUTO"), const("PSA_K1_WAVE"),
-                                                            const("PSA_K1_MFMA32"))
+    assert (_hip.K1_AUTO, _hip.K1_WAVE, _hip.K1_MFMA32, _hip.K1_SPLIT_BF16) == (
+        const("PSA_K1_AUTO"), const("PSA_K1_WAVE"), const("PSA_K1_MFMA32"), const("PSA_K1_SPLIT_BF16"))
     assert _hip.UNIQUE_ID_BYTES == const("PSA_UNIQUE_ID_BYTES")
 
 

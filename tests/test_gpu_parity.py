@@ -65,7 +65,7 @@ def test_mean_positions_is_bit_exact(engine, trajs):
     np.testing.assert_array_equal(engine.mean_positions(1), O.mean_positions(pos))
 
 
-@pytest.mark.parametrize("k1", ["auto", "mfma32", "wave"])
+@pytest.mark.parametrize("k1", ["auto", "mfma32", "wave", "bf16x3"])
 @pytest.mark.parametrize("idx", [None, [3, 9, 9, 60, 1, 17, 33]])
 @pytest.mark.parametrize("disp", [False, True])
 def test_projection_before_fft(engine, trajs, k1, idx, disp):
@@ -73,7 +73,8 @@ def test_projection_before_fft(engine, trajs, k1, idx, disp):
     d = trajs["a"]
     mean = O.mean_positions(d["positions"])
     _, kv = make_calculator(d).get_k_path([1, 1, 0], 2.0, 11)
-    engine.set_k1({"auto": _hip.K1_AUTO, "mfma32": _hip.K1_MFMA32, "wave": _hip.K1_WAVE}[k1])
+    engine.set_k1({"auto": _hip.K1_AUTO, "mfma32": _hip.K1_MFMA32, "wave": _hip.K1_WAVE,
+                   "bf16x3": _hip.K1_SPLIT_BF16}[k1])
     try:
         src = d["positions"] if disp else d["velocities"]
         engine.ensure_resident(1 if disp else 0, src)
@@ -183,7 +184,8 @@ def test_kernels_agree_with_each_other(engine, n_atoms, n_k):
     mags, vecs = calc.get_k_path("xyz", 2.0, n_k)
     out = {}
     try:
-        for name, sel in (("auto", _hip.K1_AUTO), ("mfma32", _hip.K1_MFMA32), ("wave", _hip.K1_WAVE)):
+        for name, sel in (("auto", _hip.K1_AUTO), ("mfma32", _hip.K1_MFMA32), ("wave", _hip.K1_WAVE),
+                          ("bf16x3", _hip.K1_SPLIT_BF16)):
             engine.set_k1(sel)
             out[name] = calc.calculate(mags, vecs).sed
     finally:

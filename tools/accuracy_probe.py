@@ -38,7 +38,7 @@ ref, _, _ = O.calculate(pos, vel, types, spec.dt_ps, kv)
 eng = _hip.Engine(0)
 eng.ensure_resident(0, vel)
 res = {"oracle(f32)": ref}
-for name, sel in (("split", _hip.K1_AUTO), ("mfma32", _hip.K1_MFMA32)):
+for name, sel in (("f16x2", _hip.K1_AUTO), ("bf16x3", _hip.K1_SPLIT_BF16), ("mfma32", _hip.K1_MFMA32)):
     eng.set_k1(sel)
     res[name] = eng.calculate(0, mean, kv)
 den = np.abs(I64).max()

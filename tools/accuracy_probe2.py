@@ -26,7 +26,7 @@ arg = np.dot(kv, mean.T).astype(np.float64)
 q64 = np.einsum("tac,ka->kct", vel.astype(np.float64), np.exp(1j * arg))
 eng = _hip.Engine(0)
 eng.ensure_resident(0, vel)
-for name, sel in (("split", _hip.K1_AUTO), ("mfma32", _hip.K1_MFMA32)):
+for name, sel in (("f16x2", _hip.K1_AUTO), ("bf16x3", _hip.K1_SPLIT_BF16), ("mfma32", _hip.K1_MFMA32)):
     eng.set_k1(sel)
     q = eng.debug_project_only(0, mean, kv)
     d = np.abs(q - q64)
@@ -44,7 +44,7 @@ for name, sel in (("split", _hip.K1_AUTO), ("mfma32", _hip.K1_MFMA32)):
 print("---- after the FFT ----")
 S64 = (np.fft.fft(q64, axis=2) / T).transpose(2, 0, 1)          # (T,K,3)
 I64 = np.sum(np.abs(S64) ** 2, axis=-1)
-for name, sel in (("split", _hip.K1_AUTO), ("mfma32", _hip.K1_MFMA32)):
+for name, sel in (("f16x2", _hip.K1_AUTO), ("bf16x3", _hip.K1_SPLIT_BF16), ("mfma32", _hip.K1_MFMA32)):
     eng.set_k1(sel)
     S = eng.calculate(0, mean, kv).astype(np.complex128)
     I = np.sum(np.abs(S) ** 2, axis=-1)
