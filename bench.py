@@ -202,15 +202,17 @@ def main():
         else:
             achieved, peak, unit = algo_bytes / (k1_avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
         split = args.k1 != "mfma32"          # every velocity-mode group runs the split kernel
-        split_name = {"auto": "2xf16", "bf16x3": "3xbf16", "mfma32": ""}[args.k1]
-        kernel_name = (f"k1_split_kernel (k-projection, {split_name} split-precision MFMA, fp32-equivalent)" if split
+        split_name = {"auto": "2xf16" if K > 32 else "3xbf16", "bf16x3": "3xbf16", "mfma32": ""}[args.k1]
+        kernel_name = ("k1_pair_kernel (k-projection, 2xf16 split-precision MFMA, fp32-equivalent)" if args.k1 == "auto" and K > 32
+                       else f"k1_split_kernel (k-projection, 3xbf16 split-precision MFMA, fp32-equivalent)" if split
                        else "k1_mfma_kernel (k-projection, exact-fp32 MFMA)")
         roof_note = ("achieved = algorithmic 12 flop/unit over the kernel time, priced against the fp32 "
                      "matrix-core peak (the precision the path delivers); frac > 1 is the split-precision gain")
         executed = None
         if split:
-            ex_rate = SPLIT_MFMA_FLOP_PER_UNIT[args.k1] * per_launch_units / (k1_avg_ms * 1e-3) / 1e12
-            executed = {"what": f"16-bit MFMA flop actually issued ({SPLIT_MFMA_FLOP_PER_UNIT[args.k1] // 12} "
+            issued = SPLIT_MFMA_FLOP_PER_UNIT["auto" if split_name == "2xf16" else "bf16x3"]
+            ex_rate = issued * per_launch_units / (k1_avg_ms * 1e-3) / 1e12
+            executed = {"what": f"16-bit MFMA flop actually issued ({issued // 12} "
                                 f"products per fp32 product)",
                         "rate": ex_rate, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": ex_rate / PEAK_BF16_MFMA_TFLOPS}

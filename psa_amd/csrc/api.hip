@@ -163,7 +163,7 @@ int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, const int* d_i
     // group; exact-fp32 MFMA kernel for displacement mode
     g->split = 0;
     const bool autosel = c->k1_selector == PSA_K1_AUTO;
-    if (autosel && k1_direct_eligible(d_idx, g->N_tot, n_g, K_local, disp)) {
+    if (autosel && k1_pair_eligible(d_idx, g->N_tot, n_g, K_local, disp)) {
         PSA_TRY(slot_absmax(c, slot));
         g->vscale = k1_f16_vscale(c->slot[slot].absmax_bits);
         if (g->vscale > 0.f) g->split = 2;
@@ -173,7 +173,7 @@ int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, const int* d_i
         g->split = 3;
     if (g->split == 2) {
         g->m_blk = 128;
-        g->A_pad = k1_direct_atom_pad(n_g);
+        g->A_pad = k1_pair_atom_pad(n_g);
     } else {
         g->m_blk = g->split ? k1_split_block_rows((int)K_local) : k1_mfma_block_rows((int)K_local);
     }
@@ -206,7 +206,7 @@ int project_group(psa_ctx* c, int slot, const int* d_idx, const ProjGeom& g, boo
         StageTimer st(c, PSA_T_PROJECT);
         const float* d_v = c->slot[slot].buf.as<float>();
         if (g.split == 2)
-            PSA_TRY(launch_k1_direct(c, d_v, c->d_phase.ptr, d_q, g));
+            PSA_TRY(launch_k1_pair(c, d_v, c->d_phase.ptr, d_q, g));
         else if (split)
             PSA_TRY(launch_k1_split(c, d_v, c->d_phase.ptr, d_idx, d_q, g));
         else if (c->k1_selector == PSA_K1_WAVE)
@@ -349,12 +349,11 @@ int psa_data_alloc(psa_ctx* c, int slot, int64_t T, int64_t N) {
     DataSlot& s = c->slot[slot];
     s.valid = false;
     s.absmax_known = false;
-    // 4 KiB of zeros behind the array: the split projection kernels pad the atom axis (to 32, or
-    // 256 atoms in k1_direct.hip) and read up to 255 atoms past the final row, multiplied by zero
-    // phase columns
+    // 1 KiB of zeros behind the array: the split projection kernels pad the atom axis (to 32 atoms,
+    // 64 in k1_pair.hip) and read up to 63 atoms past the final row, multiplied by zero phase columns
     const size_t bytes = (size_t)T * N * 3 * sizeof(float);
-    PSA_TRY(s.buf.reserve(bytes + 4096));
-    PSA_HIP_CHECK(hipMemsetAsync((char*)s.buf.ptr + bytes, 0, 4096, c->stream));
+    PSA_TRY(s.buf.reserve(bytes + 1024));
+    PSA_HIP_CHECK(hipMemsetAsync((char*)s.buf.ptr + bytes, 0, 1024, c->stream));
     s.T = T;
     s.N = N;
     s.valid = true;

@@ -1,4 +1,4 @@
-// Device helpers of the "2 x f16" split-precision projection kernel (k1_direct.hip): the precision
+// Device helpers of the "2 x f16" split-precision projection kernel (k1_pair.hip): the precision
 // policy, the register split of float32 operands into two float16 pieces, the phase-table tile
 // image.
 #pragma once
@@ -48,12 +48,11 @@ __device__ __forceinline__ F16x2::v8 cat4(F16x2::v2 a, F16x2::v2 b, F16x2::v2 c,
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 // raw: a lane's 8 atoms x 3 components as they lie in HBM (24 floats, component-minor, in 6
-// register quads).  Component CC of atom I:
+// register quads).  B fragments of component CC: b[piece] = the 8 atoms of this lane's frame
 template <int I, int CC>
 __device__ __forceinline__ float relem(const f32x4 (&raw)[6]) {
     return raw[(3 * I + CC) >> 2][(3 * I + CC) & 3];
 }
-// B fragments of component CC: b[piece] = the 8 atoms of this lane's frame
 template <int CC>
 __device__ __forceinline__ void split_component(const f32x4 (&raw)[6], float s, F16x2::v8 (&b)[2]) {
     F16x2::v2 lead[4], rest[4];
@@ -64,10 +63,9 @@ __device__ __forceinline__ void split_component(const f32x4 (&raw)[6], float s, 
     b[0] = cat4(lead[0], lead[1], lead[2], lead[3]);
     b[1] = cat4(rest[0], rest[1], rest[2], rest[3]);
 }
-
 // index of element (piece, row m, atom a) in the phase-table image: [M block][atom stage]
-// [piece][row][32 atoms]; the four 16-byte slots of a row are XOR-swizzled by g((row>>2)&3),
-// g = {0,2,3,1} packed as 0x78, which makes the A-fragment ds_read_b128 conflict-free
+// [piece][row][32 atoms]; the four 16-byte slots of a row (8 atoms each) are XOR-swizzled by
+// g((row>>2)&3), g = {0,2,3,1} packed as 0x78, which makes the A-fragment ds_read_b128 conflict-free
 __host__ __device__ inline size_t pf16_tile_index(int piece, int m, int a, int m_blk, int n_stage) {
     const int    row = m % m_blk, al = a % K1_BA;
     const size_t tile = ((size_t)(m / m_blk) * n_stage + a / K1_BA) * ((size_t)F16x2::NP * m_blk * K1_BA);

@@ -122,7 +122,7 @@ struct ProjGeom {
     int     K = 0;        // k-vectors (rows of the output)
     int     M_pad = 0;    // 2K rounded up to the variant's M block
     int     m_blk = 0;    // rows of P per workgroup (variant)
-    int     split = 0;    // 0: float32 kernels; 2: "2 x f16" kernel (k1_direct.hip); 3: "3 x bf16" (k1_split.hip)
+    int     split = 0;    // 0: float32 kernels; 2: "2 x f16" kernel (k1_pair.hip); 3: "3 x bf16" (k1_split.hip)
     float   vscale = 0.f; // split == 2: power of two applied to d (from the slot's largest magnitude)
 };
 
@@ -188,14 +188,14 @@ int    launch_phase_table_split(psa_ctx* c, const float* d_kvec, const float* d_
 int    launch_k1_split(psa_ctx* c, const float* d_v, const void* d_phase, const int* d_idx, float2* d_q,
                        const ProjGeom& g);
 
-// --- k1_direct.hip ("2 x f16": whole-trajectory groups, 2K > 64)
-bool   k1_direct_eligible(const int* d_idx, int64_t N_tot, int64_t n_g, int64_t K, bool displacements);
-int    k1_direct_atom_pad(int64_t n_g);
+// --- k1_pair.hip ("2 x f16": whole-trajectory groups, 2K > 64)
+bool   k1_pair_eligible(const int* d_idx, int64_t N_tot, int64_t n_g, int64_t K, bool displacements);
+int    k1_pair_atom_pad(int64_t n_g);
 float  k1_f16_vscale(unsigned absmax_bits);
 size_t pf16_table_bytes(int M_pad, int A_pad);
 int    launch_phase_table_f16(psa_ctx* c, const float* d_kvec, const float* d_mean_all, void* d_phase,
                               const ProjGeom& g);
-int    launch_k1_direct(psa_ctx* c, const float* d_v, const void* d_phase, float2* d_q, const ProjGeom& g);
+int    launch_k1_pair(psa_ctx* c, const float* d_v, const void* d_phase, float2* d_q, const ProjGeom& g);
 
 // --- k2_epilogue.hip
 int launch_scale_transpose_c64(psa_ctx* c, const float2* d_slab, float2* d_out, int64_t T, int64_t K);

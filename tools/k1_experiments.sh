@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build side copies of libpsa_hip.so with timing experiments compiled into the large-K projection
-# kernel (see PSA_K1_EXPERIMENT in psa_amd/csrc/k1_direct.hip) and time configuration 3 with each:
+# kernel (see PSA_K1_EXPERIMENT in psa_amd/csrc/k1_pair.hip) and time configuration 3 with each:
 #   tools/k1_experiments.sh build 1 2 4 ...      (in the build container)
 #   tools/k1_experiments.sh run 1 2 4 ...        (on the GPU box; writes gpurun_out/k1_experiments.txt)
 set -e
@@ -13,9 +13,9 @@ if [ "$mode" = build ]; then
   make -C "$SRC" >/dev/null
   for x in "$@"; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I"$ROOT/include" -I"$SRC" -fno-fast-math \
-      -ffp-contract=on -fno-slp-vectorize -DPSA_K1_EXPERIMENT=$x -c "$SRC/k1_direct.hip" -o "$OUT/k1_direct_x$x.o" 2>/dev/null
-    objs=$(ls "$SRC"/build/*.o | grep -v k1_direct.o)
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$OUT/libpsa_hip_x$x.so" $objs "$OUT/k1_direct_x$x.o" \
+      -ffp-contract=on -fno-slp-vectorize -DPSA_K1_EXPERIMENT=$x -c "$SRC/k1_pair.hip" -o "$OUT/k1_pair_x$x.o" 2>/dev/null
+    objs=$(ls "$SRC"/build/*.o | grep -v k1_pair.o)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$OUT/libpsa_hip_x$x.so" $objs "$OUT/k1_pair_x$x.o" \
       -L/opt/rocm/lib -lrocfft -lrccl -Wl,-rpath,/opt/rocm/lib 2>/dev/null
     echo "built $OUT/libpsa_hip_x$x.so"
   done
