@@ -202,8 +202,12 @@ def main():
         else:
             achieved, peak, unit = algo_bytes / (k1_avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
         split = args.k1 != "mfma32"          # every velocity-mode group runs the split kernel
-        split_name = {"auto": "2xf16" if K > 32 else "3xbf16", "bf16x3": "3xbf16", "mfma32": ""}[args.k1]
-        kernel_name = ("k1_pair_kernel (k-projection, 2xf16 split-precision MFMA, fp32-equivalent)" if args.k1 == "auto" and K > 32
+        # the library's own rule (api.hip make_geom): "2 x f16" for whole-trajectory groups with more
+        # than 16 k-vectors on this rank, "3 x bf16" for index-list groups and short k-lists
+        whole = dev_groups is None
+        f16 = args.k1 == "auto" and k_local > 16 and whole
+        split_name = "2xf16" if f16 else "3xbf16" if split else ""
+        kernel_name = ("k1_pair_kernel (k-projection, 2xf16 split-precision MFMA, fp32-equivalent)" if f16
                        else f"k1_split_kernel (k-projection, 3xbf16 split-precision MFMA, fp32-equivalent)" if split
                        else "k1_mfma_kernel (k-projection, exact-fp32 MFMA)")
         roof_note = ("achieved = algorithmic 12 flop/unit over the kernel time, priced against the fp32 "
@@ -248,8 +252,8 @@ def main():
         # WRITE_SIZE in separate runs; FETCH_SIZE doubled for 16-byte/lane streaming reads as
         # MI355X_MICROARCH.md prescribes; counts L2->fabric requests, Infinity-Cache hits included)
         # -- only when this run is the profiled workload
-        pmc = ROOT / "profiles" / {"auto": "r1g_C3_pmc_fetch_write.json", "bf16x3": "r1d_C3_pmc_fetch_write.json",
-                                   "mfma32": "r1b_C3_pmc_fetch_write.json"}[args.k1]
+        pmc = ROOT / "profiles" / ("r1g_C3_pmc_fetch_write.json" if f16 else "r1d_C3_pmc_fetch_write.json" if split
+                                   else "r1b_C3_pmc_fetch_write.json")
         if args.config == "C3" and K == 256 and world == 1 and not intensity_out and pmc.exists():
             summ = json.loads(pmc.read_text())["k1_summary"]
             out["roofline"]["traffic"] = summ["fetch_bytes_corrected_x2"] + summ["write_bytes"]

@@ -172,7 +172,7 @@ int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, const int* d_i
         k1_split_eligible(d_idx, g->N_tot, n_g, disp))
         g->split = 3;
     if (g->split == 2) {
-        g->m_blk = 128;
+        g->m_blk = k1_pair_block_rows((int)K_local);
         g->A_pad = k1_pair_atom_pad(n_g);
     } else {
         g->m_blk = g->split ? k1_split_block_rows((int)K_local) : k1_mfma_block_rows((int)K_local);

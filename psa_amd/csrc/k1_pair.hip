@@ -38,18 +38,19 @@
 
 namespace psa {
 
+template <int MT16_>
 struct K1qCfg {
-    static constexpr int MT16 = 4;                 // row tiles of 16 per wavefront: 64 rows
-    static constexpr int M_BLK = 128;              // two row halves
+    static constexpr int MT16 = MT16_;             // row tiles of 16 per wavefront: 64 rows (or 32 for short k-lists)
+    static constexpr int M_BLK = 32 * MT16;        // two row halves
     static constexpr int T_BLK = 64;               // four frame groups of 16
     static constexpr int FOLD = 8;                 // stages per MFMA chain
     static constexpr int RING = 3;                 // slots: stage s+1 being read, s+2 and s+3 in flight
     static constexpr int P_STAGE_BYTES = F16x2::NP * M_BLK * K1_BA * 2;    // 16 KiB
-    static constexpr int P_DMA = P_STAGE_BYTES / 1024 / 8;                 // pieces per wavefront: 2
+    static constexpr int P_DMA = P_STAGE_BYTES / 1024 / 8;                 // pieces per wavefront: 2 (or 1)
     static constexpr int V_DMA = 3;                                        // half of a frame group's 6 KiB
     static constexpr int RAW_GROUP_BYTES = 6 * 1024;                       // 16 rows x 384 B
     static constexpr int RAW_STAGE_BYTES = 4 * RAW_GROUP_BYTES;
-    static constexpr int STAGE_BYTES = P_STAGE_BYTES + RAW_STAGE_BYTES;    // 40 KiB
+    static constexpr int STAGE_BYTES = P_STAGE_BYTES + RAW_STAGE_BYTES;    // 40 (32) KiB
     static constexpr int LDS_BYTES = RING * STAGE_BYTES;
     static constexpr int BATCH = P_DMA + V_DMA;    // VMEM instructions per stage and wavefront
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -72,10 +73,11 @@ __device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_byte_addr)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory");
 }
 
+template <int MT16_>
 __global__ void __launch_bounds__(512, 1)
 k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, float2* __restrict__ Q, int64_t T,
                int64_t N_tot, int n_stage, int K, int n_mblk, int n_tblk, float vscale, float qscale) {
-    using C = K1qCfg;
+    using C = K1qCfg<MT16_>;
     using PR = F16x2;
     using E8 = PR::v8;
     constexpr int NP = PR::NP, MT16 = C::MT16;
@@ -131,7 +133,7 @@ k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, flo
 
     // ---- LDS read addresses ---------------------------------------------------------------------
     const int      gsw = (0x78 >> (2 * ((r16 >> 2) & 3))) & 3;     // P' slot swizzle: k1_f16.h
-    const unsigned p_lane = lds0 + (wh * 64 + r16) * (K1_BA * 2) + ((q ^ gsw) << 4);
+    const unsigned p_lane = lds0 + (wh * (C::M_BLK / 2) + r16) * (K1_BA * 2) + ((q ^ gsw) << 4);
     const unsigned raw_lane = lds0 + C::P_STAGE_BYTES + wf * C::RAW_GROUP_BYTES + r16 * (K1_VROW * 4);
     E8             a[NP][MT16];
     E8             bs[2][3][NP];                       // B fragments of stage k: bs[k & 1][component][piece]
@@ -250,7 +252,7 @@ k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, flo
 
     // epilogue: register j of lane (r16, q) is row 4q + j, column r16 of its 16x16 tile; rows
     // 2p, 2p+1 are the cos / sin rows of one k -> one complex64 per lane and register pair
-    const int     m0 = mb * C::M_BLK + wh * 64;
+    const int     m0 = mb * C::M_BLK + wh * (C::M_BLK / 2);
     const int64_t t = t0 + r16;
     if (t < T) {
 #pragma unroll
@@ -323,28 +325,36 @@ float k1_f16_vscale(unsigned absmax_bits) {
     return s.f;
 }
 
-// whole trajectory in its own order (the DMA copies whole frame rows), more than 32 k-vectors
+// whole trajectory in its own order (the DMA copies whole frame rows), more than 16 k-vectors
 bool k1_pair_eligible(const int* d_idx, int64_t N_tot, int64_t n_g, int64_t K, bool displacements) {
-    return !displacements && d_idx == nullptr && n_g == N_tot && N_tot % 4 == 0 && 2 * K > 64;
+    return !displacements && d_idx == nullptr && n_g == N_tot && N_tot % 4 == 0 && 2 * K > 32;
 }
 
 int k1_pair_atom_pad(int64_t n_g) { return (int)((n_g + 63) / 64 * 64); }
 
-int launch_k1_pair(psa_ctx* c, const float* d_v, const void* d_phase, float2* d_q, const ProjGeom& g) {
-    using C = K1qCfg;
-    PSA_REQUIRE(g.m_blk == C::M_BLK && g.M_pad % C::M_BLK == 0, "projection kernel needs 128-row M blocks");
-    PSA_REQUIRE(g.A_pad % (2 * K1_BA) == 0 && g.A_pad > 0, "projection kernel needs the atom axis padded to %d", 2 * K1_BA);
-    PSA_REQUIRE(g.n_g == g.N_tot && g.N_tot % 4 == 0, "projection kernel takes whole-trajectory groups, N %% 4 == 0");
-    PSA_REQUIRE(g.vscale > 0.f, "f16 split kernel needs the array's scale");
+template <int MT16>
+static int launch_pair_variant(psa_ctx* c, const float* d_v, const void* d_phase, float2* d_q, const ProjGeom& g) {
+    using C = K1qCfg<MT16>;
     const int     n_mblk = g.M_pad / C::M_BLK;
     const int64_t n_tblk = (g.T + C::T_BLK - 1) / C::T_BLK;
     const int64_t grid = ((n_tblk + 7) / 8) * 8 * n_mblk;
     PSA_REQUIRE(grid < (1ll << 31) && n_tblk < (1ll << 31), "projection grid too large");
     const float qscale = 1.f / (g.vscale * F16x2::P_SCALE);           // powers of two: exact
-    hipLaunchKernelGGL(k1_pair_kernel, dim3((unsigned)grid), dim3(512), 0, c->stream, d_v, (const _Float16*)d_phase, d_q,
-                       g.T, g.N_tot, g.A_pad / K1_BA, g.K, n_mblk, (int)n_tblk, g.vscale, qscale);
+    hipLaunchKernelGGL(k1_pair_kernel<MT16>, dim3((unsigned)grid), dim3(512), 0, c->stream, d_v, (const _Float16*)d_phase,
+                       d_q, g.T, g.N_tot, g.A_pad / K1_BA, g.K, n_mblk, (int)n_tblk, g.vscale, qscale);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
+}
+
+// 128-row M blocks; 64-row blocks for k-lists of at most 32 (a one-block launch wastes nothing)
+int k1_pair_block_rows(int K) { return 2 * K <= 64 ? 64 : 128; }
+
+int launch_k1_pair(psa_ctx* c, const float* d_v, const void* d_phase, float2* d_q, const ProjGeom& g) {
+    PSA_REQUIRE((g.m_blk == 128 || g.m_blk == 64) && g.M_pad % g.m_blk == 0, "projection kernel needs 64- or 128-row M blocks");
+    PSA_REQUIRE(g.A_pad % (2 * K1_BA) == 0 && g.A_pad > 0, "projection kernel needs the atom axis padded to %d", 2 * K1_BA);
+    PSA_REQUIRE(g.n_g == g.N_tot && g.N_tot % 4 == 0, "projection kernel takes whole-trajectory groups, N %% 4 == 0");
+    PSA_REQUIRE(g.vscale > 0.f, "f16 split kernel needs the array's scale");
+    return g.m_blk == 128 ? launch_pair_variant<4>(c, d_v, d_phase, d_q, g) : launch_pair_variant<2>(c, d_v, d_phase, d_q, g);
 }
 
 }  // namespace psa

@@ -191,6 +191,7 @@ int    launch_k1_split(psa_ctx* c, const float* d_v, const void* d_phase, const 
 // --- k1_pair.hip ("2 x f16": whole-trajectory groups, 2K > 64)
 bool   k1_pair_eligible(const int* d_idx, int64_t N_tot, int64_t n_g, int64_t K, bool displacements);
 int    k1_pair_atom_pad(int64_t n_g);
+int    k1_pair_block_rows(int K);
 float  k1_f16_vscale(unsigned absmax_bits);
 size_t pf16_table_bytes(int M_pad, int A_pad);
 int    launch_phase_table_f16(psa_ctx* c, const float* d_kvec, const float* d_mean_all, void* d_phase,

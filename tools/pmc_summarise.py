@@ -18,7 +18,7 @@ for f in root.rglob("*kernel_trace.csv"):
         dur[row["Kernel_Name"].split("(")[0]].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
 out = {}
 for name, counters in acc.items():
-    if "k1_" not in name:
+    if "k1_" not in name and "--all" not in sys.argv:
         continue
     n_disp = None
     entry = {}
