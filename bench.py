@@ -202,10 +202,9 @@ def main():
         else:
             achieved, peak, unit = algo_bytes / (k1_avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
         split = args.k1 != "mfma32"          # every velocity-mode group runs the split kernel
-        # the library's own rule (api.hip make_geom): "2 x f16" for whole-trajectory groups with more
-        # than 16 k-vectors on this rank, "3 x bf16" for index-list groups and short k-lists
-        whole = dev_groups is None
-        f16 = args.k1 == "auto" and k_local > 16 and whole
+        # the library's own rule (api.hip make_geom): "2 x f16" for velocity-mode groups with more
+        # than 16 k-vectors on this rank, "3 x bf16" for short k-lists
+        f16 = args.k1 == "auto" and k_local > 16
         split_name = "2xf16" if f16 else "3xbf16" if split else ""
         kernel_name = ("k1_pair_kernel (k-projection, 2xf16 split-precision MFMA, fp32-equivalent)" if f16
                        else f"k1_split_kernel (k-projection, 3xbf16 split-precision MFMA, fp32-equivalent)" if split

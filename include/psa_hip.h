@@ -58,8 +58,8 @@ extern "C" {
 
 /* projection-kernel selector (diagnostics; PSA_K1_AUTO is the product path) */
 #define PSA_K1_AUTO   0  /* split-precision (fp32-equivalent) MFMA kernels for velocity data: "2 x f16"
-                            for whole-trajectory groups with more than 32 k-vectors, "3 x bf16" for
-                            every other group; exact-fp32 MFMA kernel for displacement mode */
+                            for groups with more than 16 k-vectors, "3 x bf16" below that and for
+                            arrays holding NaN/Inf; exact-fp32 MFMA kernel for displacement mode */
 #define PSA_K1_WAVE   1  /* LDS-staged VALU kernel with wavefront shuffle sums       */
 #define PSA_K1_MFMA32 2  /* always the exact-fp32 MFMA tile kernel                   */
 #define PSA_K1_SPLIT_BF16 3  /* "3 x bf16" split-precision kernel for every velocity-mode group */

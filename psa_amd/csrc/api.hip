@@ -190,7 +190,7 @@ int project_group(psa_ctx* c, int slot, const int* d_idx, const ProjGeom& g, boo
     {
         StageTimer st(c, PSA_T_PHASE);
         if (g.split == 2)
-            PSA_TRY(launch_phase_table_f16(c, c->d_kvec.as<float>(), c->d_mean_all.as<float>(), c->d_phase.ptr, g));
+            PSA_TRY(launch_phase_table_f16(c, c->d_kvec.as<float>(), c->d_mean_all.as<float>(), d_idx, c->d_phase.ptr, g));
         else if (split)
             PSA_TRY(launch_phase_table_split(c, c->d_kvec.as<float>(), c->d_mean_all.as<float>(), d_idx,
                                              c->d_phase.ptr, g));
@@ -206,7 +206,7 @@ int project_group(psa_ctx* c, int slot, const int* d_idx, const ProjGeom& g, boo
         StageTimer st(c, PSA_T_PROJECT);
         const float* d_v = c->slot[slot].buf.as<float>();
         if (g.split == 2)
-            PSA_TRY(launch_k1_pair(c, d_v, c->d_phase.ptr, d_q, g));
+            PSA_TRY(launch_k1_pair(c, d_v, c->d_phase.ptr, d_idx, d_q, g));
         else if (split)
             PSA_TRY(launch_k1_split(c, d_v, c->d_phase.ptr, d_idx, d_q, g));
         else if (c->k1_selector == PSA_K1_WAVE)

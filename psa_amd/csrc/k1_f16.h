@@ -63,6 +63,18 @@ __device__ __forceinline__ void split_component(const f32x4 (&raw)[6], float s, 
     b[0] = cat4(lead[0], lead[1], lead[2], lead[3]);
     b[1] = cat4(rest[0], rest[1], rest[2], rest[3]);
 }
+// the same from the gathered image: one (x, y, z, -) quad per atom
+template <int CC>
+__device__ __forceinline__ void split_component(const f32x4 (&raw)[8], float s, F16x2::v8 (&b)[2]) {
+    F16x2::v2 lead[4], rest[4];
+    split_pair(raw[0][CC], raw[1][CC], s, lead[0], rest[0]);
+    split_pair(raw[2][CC], raw[3][CC], s, lead[1], rest[1]);
+    split_pair(raw[4][CC], raw[5][CC], s, lead[2], rest[2]);
+    split_pair(raw[6][CC], raw[7][CC], s, lead[3], rest[3]);
+    b[0] = cat4(lead[0], lead[1], lead[2], lead[3]);
+    b[1] = cat4(rest[0], rest[1], rest[2], rest[3]);
+}
+
 // index of element (piece, row m, atom a) in the phase-table image: [M block][atom stage]
 // [piece][row][32 atoms]; the four 16-byte slots of a row (8 atoms each) are XOR-swizzled by
 // g((row>>2)&3), g = {0,2,3,1} packed as 0x78, which makes the A-fragment ds_read_b128 conflict-free

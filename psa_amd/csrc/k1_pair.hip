@@ -38,8 +38,9 @@
 
 namespace psa {
 
-template <int MT16_>
+template <int MT16_, bool GATHER_>
 struct K1qCfg {
+    static constexpr bool GATHER = GATHER_;        // index-list group (any order, duplicates) or N % 4 != 0
     static constexpr int MT16 = MT16_;             // row tiles of 16 per wavefront: 64 rows (or 32 for short k-lists)
     static constexpr int M_BLK = 32 * MT16;        // two row halves
     static constexpr int T_BLK = 64;               // four frame groups of 16
@@ -47,12 +48,21 @@ struct K1qCfg {
     static constexpr int RING = 3;                 // slots: stage s+1 being read, s+2 and s+3 in flight
     static constexpr int P_STAGE_BYTES = F16x2::NP * M_BLK * K1_BA * 2;    // 16 KiB
     static constexpr int P_DMA = P_STAGE_BYTES / 1024 / 8;                 // pieces per wavefront: 2 (or 1)
-    static constexpr int V_DMA = 3;                                        // half of a frame group's 6 KiB
-    static constexpr int RAW_GROUP_BYTES = 6 * 1024;                       // 16 rows x 384 B
+    // V image of a frame group.  Whole trajectory: 16 rows x 384 B in 6 pieces of 1 KiB.  Gathered:
+    // 8 pieces of (2 frames x 32 atoms x 16 B) -- one (frame, atom) triple is a 12-byte LDS-DMA
+    // element, which the hardware lays on a 16-byte pitch (tools/probes/dma12.hip) -- with 16 B of
+    // padding per piece that keeps the raw reads at 2-way conflicts.  Either way each wavefront of
+    // the pair copies half of the pieces.
+    static constexpr int V_PIECE_BYTES = GATHER ? 1024 + 16 : 1024;
+    static constexpr int V_DMA = GATHER ? 4 : 3;
+    static constexpr int RAW_GROUP_BYTES = 2 * V_DMA * V_PIECE_BYTES;
     static constexpr int RAW_STAGE_BYTES = 4 * RAW_GROUP_BYTES;
-    static constexpr int STAGE_BYTES = P_STAGE_BYTES + RAW_STAGE_BYTES;    // 40 (32) KiB
-    static constexpr int LDS_BYTES = RING * STAGE_BYTES;
-    static constexpr int BATCH = P_DMA + V_DMA;    // VMEM instructions per stage and wavefront
+    static constexpr int STAGE_BYTES = P_STAGE_BYTES + RAW_STAGE_BYTES;    // 40 (32) KiB; gathered 48.5 (40.5)
+    // gathered: a private ring of index rows (64 lanes x 4 B) per wavefront behind the stage slots
+    static constexpr int IDX_BASE = RING * STAGE_BYTES;
+    static constexpr int LDS_BYTES = IDX_BASE + (GATHER ? 8 * RING * 256 : 0);
+    static constexpr int BATCH = P_DMA + V_DMA + (GATHER ? 1 : 0);    // VMEM instructions per stage and wavefront
+    static constexpr int RAWN = GATHER ? 8 : 6;    // 16-byte reads per lane and stage
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -72,12 +82,24 @@ __device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_byte_addr)
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory");
 }
+// 12 bytes per lane, landing at dst + lane * 16
+__device__ __forceinline__ void lds_dma12(const void* g, unsigned lds_byte_addr) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %0, off" ::"v"(g), "s"(dst) : "memory");
+}
+// 4 bytes per lane, landing at dst + lane * 4
+__device__ __forceinline__ void lds_dma4(const void* g, unsigned lds_byte_addr) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(dst) : "memory");
+}
 
-template <int MT16_>
+template <int MT16_, bool GATHER_>
 __global__ void __launch_bounds__(512, 1)
-k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, float2* __restrict__ Q, int64_t T,
-               int64_t N_tot, int n_stage, int K, int n_mblk, int n_tblk, float vscale, float qscale) {
-    using C = K1qCfg<MT16_>;
+k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, const int* __restrict__ idx,
+               float2* __restrict__ Q, int64_t T, int64_t N_tot, int n_g, int n_stage, int K, int n_mblk, int n_tblk,
+               float vscale, float qscale) {
+    using C = K1qCfg<MT16_, GATHER_>;
+    constexpr bool GATHER = GATHER_;
     using PR = F16x2;
     using E8 = PR::v8;
     constexpr int NP = PR::NP, MT16 = C::MT16;
@@ -101,43 +123,72 @@ k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, flo
     const int     last = n_stage - 1;
 
     // ---- DMA sources ----------------------------------------------------------------------------
-    // V: the frame group's 16 x 24 image of 16-byte slots, pieces 3 wh .. 3 wh + 2 of its 6; the
-    // slots of a row are XOR-swizzled on the way in (the source address carries the swizzle, the
-    // LDS image is written linearly) so that the 96-byte reads below are conflict-free.  Rows past
-    // the end: a finite filler row.
+    // Whole trajectory: the frame group's 16 x 24 image of 16-byte slots, pieces 3 wh .. 3 wh + 2 of
+    // its 6; the slots of a row are XOR-swizzled on the way in (the source address carries the
+    // swizzle, the LDS image is written linearly) so that the 96-byte reads below are conflict-free.
+    // Gathered: piece j covers frames 2j, 2j+1 x the stage's 32 atoms; lane l serves atom column
+    // l & 31 of frame 2j + (l >> 5), so it keeps 4 row pointers and needs ONE atom index per stage.
+    // Rows past the end: a finite filler row.
     const float* vp[C::V_DMA];
 #pragma unroll
     for (int j = 0; j < C::V_DMA; ++j) {
-        const int L = (wh * C::V_DMA + j) * 64 + lane;
-        const int row = L / 24, phys = L - row * 24;
-        int64_t   t = t0 + row;
-        if (t >= T) t = T - 1;
-        vp[j] = V + t * 3 * N_tot + 4 * vs_phys_slot(phys, row);
+        if constexpr (GATHER) {
+            int64_t t = t0 + 2 * (wh * C::V_DMA + j) + (lane >> 5);
+            if (t >= T) t = T - 1;
+            vp[j] = V + t * 3 * N_tot;
+        } else {
+            const int L = (wh * C::V_DMA + j) * 64 + lane;
+            const int row = L / 24, phys = L - row * 24;
+            int64_t   t = t0 + row;
+            if (t >= T) t = T - 1;
+            vp[j] = V + t * 3 * N_tot + 4 * vs_phys_slot(phys, row);
+        }
     }
     const unsigned char* pp = reinterpret_cast<const unsigned char*>(Pb) + (size_t)mb * n_stage * C::P_STAGE_BYTES +
                               16 * (w * C::P_DMA * 64 + lane);
-    // piece i of this wavefront's BATCH for stage st (clamped) -> slot: P' pieces first, then V
-    auto dma_piece = [&](int i, int st, int slot) {
+    // Gathered: position of this lane's atom in the group at stage st (columns past the group's end
+    // carry P' = 0: any valid atom), its index straight from HBM (prologue), and the private LDS
+    // ring the index rows of later stages travel through (row k in slot k % 3).
+    auto pos_of = [&](int st) {
+        int pos = (st < last ? st : last) * K1_BA + (lane & 31);
+        return pos < n_g ? pos : n_g - 1;
+    };
+    const unsigned idx_ring = lds0 + C::IDX_BASE + w * (C::RING * 256);
+    // this wavefront's BATCH for stage st (clamped) -> slot: P' pieces first, then V (gathered: with
+    // the atom index `atom`), then the index row of stage st + 2
+    auto dma_stage = [&](int st, int slot, int atom) {
         const int      sc = st < last ? st : last;
         const unsigned dst = lds0 + slot * C::STAGE_BYTES;
-        if (i < C::P_DMA)
-            lds_dma16(pp + (size_t)sc * C::P_STAGE_BYTES + 1024 * i, dst + 1024 * (w * C::P_DMA + i));
-        else
-            lds_dma16(vp[i - C::P_DMA] + (size_t)sc * K1_VROW,
-                      dst + C::P_STAGE_BYTES + wf * C::RAW_GROUP_BYTES + 1024 * (wh * C::V_DMA + i - C::P_DMA));
-    };
-    auto dma_stage = [&](int st, int slot) {
 #pragma unroll
-        for (int i = 0; i < C::BATCH; ++i) dma_piece(i, st, slot);
+        for (int i = 0; i < C::P_DMA; ++i)
+            lds_dma16(pp + (size_t)sc * C::P_STAGE_BYTES + 1024 * i, dst + 1024 * (w * C::P_DMA + i));
+        const unsigned vdst = dst + C::P_STAGE_BYTES + wf * C::RAW_GROUP_BYTES + wh * C::V_DMA * C::V_PIECE_BYTES;
+#pragma unroll
+        for (int j = 0; j < C::V_DMA; ++j) {
+            if constexpr (GATHER) lds_dma12(vp[j] + 3 * (int64_t)atom, vdst + j * C::V_PIECE_BYTES);
+            else lds_dma16(vp[j] + (size_t)sc * K1_VROW, vdst + j * C::V_PIECE_BYTES);
+        }
+        if constexpr (GATHER) {
+            const int* src = idx ? idx + pos_of(st + 2) : nullptr;
+            // no index list (N % 4 != 0): the "index" is the position itself; keep the DMA count uniform
+            lds_dma4(idx ? (const void*)src : (const void*)(V + (lane & 31)), idx_ring + ((st + 2) % C::RING) * 256);
+        }
+    };
+    auto atom_from_ring = [&](int st) -> int {       // index of this lane's atom at stage st
+        if constexpr (!GATHER) return 0;
+        if (!idx) return pos_of(st);
+        return *reinterpret_cast<const __attribute__((address_space(3))) int*>(
+            (const lds_u8*)(size_t)(idx_ring + (st % C::RING) * 256 + 4 * lane));
     };
 
     // ---- LDS read addresses ---------------------------------------------------------------------
     const int      gsw = (0x78 >> (2 * ((r16 >> 2) & 3))) & 3;     // P' slot swizzle: k1_f16.h
     const unsigned p_lane = lds0 + (wh * (C::M_BLK / 2) + r16) * (K1_BA * 2) + ((q ^ gsw) << 4);
-    const unsigned raw_lane = lds0 + C::P_STAGE_BYTES + wf * C::RAW_GROUP_BYTES + r16 * (K1_VROW * 4);
+    const unsigned raw_lane = lds0 + C::P_STAGE_BYTES + wf * C::RAW_GROUP_BYTES +
+                              (GATHER ? (r16 >> 1) * C::V_PIECE_BYTES + (r16 & 1) * 512 + q * 128 : r16 * (K1_VROW * 4));
     E8             a[NP][MT16];
     E8             bs[2][3][NP];                       // B fragments of stage k: bs[k & 1][component][piece]
-    f32x4          raw[6];
+    f32x4          raw[C::RAWN];
     f32x4          hi[MT16][3], lo[MT16][3];           // the running MFMA chains / the float32 sums
     auto read_a_tile = [&](int mt, int slot) {
         const unsigned base = p_lane + slot * C::STAGE_BYTES;
@@ -145,11 +196,12 @@ k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, flo
         for (int p = 0; p < NP; ++p)
             a[p][mt] = *reinterpret_cast<lds_cv8*>((const lds_u8*)(size_t)(base + (p * C::M_BLK + mt * 16) * 64));
     };
-    auto read_raw = [&](int slot) {                    // atoms 8q .. 8q+7 of frame r16: six swizzled slots
+    // atoms 8q .. 8q+7 of frame r16: six swizzled 16-byte slots, or (gathered) eight (x,y,z,-) quads
+    auto read_raw = [&](int slot) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-            raw[j] = *reinterpret_cast<lds_cf32x4*>(
-                (const lds_u8*)(size_t)(raw_lane + slot * C::STAGE_BYTES + 16 * vs_phys_slot(6 * q + j, r16)));
+        for (int j = 0; j < C::RAWN; ++j)
+            raw[j] = *reinterpret_cast<lds_cf32x4*>((const lds_u8*)(size_t)(
+                raw_lane + slot * C::STAGE_BYTES + (GATHER ? 16 * j : 16 * vs_phys_slot(6 * q + j, r16))));
     };
 #pragma unroll
     for (int mt = 0; mt < MT16; ++mt)
@@ -160,9 +212,19 @@ k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, flo
         }
 
     // ---- prologue: stages 0, 1, 2 in flight; stage 0 into registers ------------------------------
-    dma_stage(0, 0);
-    dma_stage(1, 1);
-    dma_stage(2, 2);
+    {
+        // gathered: the first three index rows come straight from HBM (plain loads, before any DMA);
+        // the batches of stages 0, 1, 2 carry the index rows of stages 2, 3, 4 (row 2 is not used)
+        int a0 = 0, a1 = 0, a2 = 0;
+        if constexpr (GATHER) {
+            a0 = idx ? idx[pos_of(0)] : pos_of(0);
+            a1 = idx ? idx[pos_of(1)] : pos_of(1);
+            a2 = idx ? idx[pos_of(2)] : pos_of(2);
+        }
+        dma_stage(0, 0, a0);
+        dma_stage(1, 1, a1);
+        dma_stage(2, 2, a2);
+    }
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * C::BATCH) : "memory");      // stage 0 landed
     read_raw(0);
 #pragma unroll
@@ -198,15 +260,18 @@ k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, flo
         constexpr int  par = decltype(par_c)::value;
         constexpr bool restart = decltype(restart_c)::value;
         const int      slot1 = slot == 2 ? 0 : slot + 1;
-        if constexpr ((PSA_K1_EXPERIMENT & 1) == 0) dma_stage(s + 3, slot);
+        // gathered: the index row of stage s+3 came with the batch of stage s+1 (issued a stage ago,
+        // awaited at the end of it by the counted vmcnt)
+        if constexpr ((PSA_K1_EXPERIMENT & 1) == 0) dma_stage(s + 3, slot, atom_from_ring(s + 3));
         read_raw(slot1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < MT16; ++mt) {
             if constexpr ((PSA_K1_EXPERIMENT & 4) == 0) {
-                if (mt == 1) split_component<0>(raw, vscale, bs[par ^ 1][0]);
-                if (mt == 2) split_component<1>(raw, vscale, bs[par ^ 1][1]);
-                if (mt == 3) split_component<2>(raw, vscale, bs[par ^ 1][2]);
+                // the three components beside regions 1, 2, 3 (four row tiles) or 0, 1, 1 (two)
+                if (mt == (MT16 >= 4 ? 1 : 0)) split_component<0>(raw, vscale, bs[par ^ 1][0]);
+                if (mt == (MT16 >= 4 ? 2 : 1)) split_component<1>(raw, vscale, bs[par ^ 1][1]);
+                if (mt == (MT16 >= 4 ? 3 : 1)) split_component<2>(raw, vscale, bs[par ^ 1][2]);
             }
             mfma_tile(mt, par, restart);
 #pragma unroll
@@ -277,14 +342,16 @@ k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, flo
 // Same float32 argument / sincos as phase_table_kernel (kernels_misc.hip); only the storage differs.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-phase_table_f16_kernel(const float* __restrict__ kvec, const float* __restrict__ mean_all, _Float16* __restrict__ Pb,
-                       int K, int n_g, int A_pad, int M_pad, int m_blk) {
+phase_table_f16_kernel(const float* __restrict__ kvec, const float* __restrict__ mean_all, const int* __restrict__ idx,
+                       _Float16* __restrict__ Pb, int K, int n_g, int A_pad, int M_pad, int m_blk) {
     const int a = blockIdx.y * 256 + threadIdx.x;
     const int k = blockIdx.x;
     if (a >= A_pad || 2 * k >= M_pad) return;
     float cs[2] = {0.f, 0.f};
     if (k < K && a < n_g) {
-        const float rx = mean_all[3 * (size_t)a + 0], ry = mean_all[3 * (size_t)a + 1], rz = mean_all[3 * (size_t)a + 2];
+        const int   src = idx ? idx[a] : a;
+        const float rx = mean_all[3 * (size_t)src + 0], ry = mean_all[3 * (size_t)src + 1],
+                    rz = mean_all[3 * (size_t)src + 2];
         const float kx = kvec[3 * k + 0], ky = kvec[3 * k + 1], kz = kvec[3 * k + 2];
         const float arg = __fmaf_rn(kz, rz, __fmaf_rn(ky, ry, __fmul_rn(kx, rx)));
         sincosf(arg, &cs[1], &cs[0]);
@@ -301,9 +368,10 @@ phase_table_f16_kernel(const float* __restrict__ kvec, const float* __restrict__
 
 size_t pf16_table_bytes(int M_pad, int A_pad) { return (size_t)M_pad * A_pad * 2 * F16x2::NP; }
 
-int launch_phase_table_f16(psa_ctx* c, const float* d_kvec, const float* d_mean_all, void* d_phase, const ProjGeom& g) {
+int launch_phase_table_f16(psa_ctx* c, const float* d_kvec, const float* d_mean_all, const int* d_idx, void* d_phase,
+                           const ProjGeom& g) {
     dim3 grid(g.M_pad / 2, (g.A_pad + 255) / 256);
-    hipLaunchKernelGGL(phase_table_f16_kernel, grid, dim3(256), 0, c->stream, d_kvec, d_mean_all, (_Float16*)d_phase,
+    hipLaunchKernelGGL(phase_table_f16_kernel, grid, dim3(256), 0, c->stream, d_kvec, d_mean_all, d_idx, (_Float16*)d_phase,
                        g.K, g.n_g, g.A_pad, g.M_pad, g.m_blk);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
@@ -325,23 +393,27 @@ float k1_f16_vscale(unsigned absmax_bits) {
     return s.f;
 }
 
-// whole trajectory in its own order (the DMA copies whole frame rows), more than 16 k-vectors
+// every velocity-mode group with more than 16 k-vectors (whole trajectory in its own order: row
+// DMA; index lists or N % 4 != 0: per-atom gather DMA)
 bool k1_pair_eligible(const int* d_idx, int64_t N_tot, int64_t n_g, int64_t K, bool displacements) {
-    return !displacements && d_idx == nullptr && n_g == N_tot && N_tot % 4 == 0 && 2 * K > 32;
+    (void)d_idx; (void)N_tot; (void)n_g;
+    return !displacements && 2 * K > 32;
 }
 
 int k1_pair_atom_pad(int64_t n_g) { return (int)((n_g + 63) / 64 * 64); }
 
-template <int MT16>
-static int launch_pair_variant(psa_ctx* c, const float* d_v, const void* d_phase, float2* d_q, const ProjGeom& g) {
-    using C = K1qCfg<MT16>;
+template <int MT16, bool GATHER>
+static int launch_pair_variant(psa_ctx* c, const float* d_v, const void* d_phase, const int* d_idx, float2* d_q,
+                               const ProjGeom& g) {
+    using C = K1qCfg<MT16, GATHER>;
     const int     n_mblk = g.M_pad / C::M_BLK;
     const int64_t n_tblk = (g.T + C::T_BLK - 1) / C::T_BLK;
     const int64_t grid = ((n_tblk + 7) / 8) * 8 * n_mblk;
     PSA_REQUIRE(grid < (1ll << 31) && n_tblk < (1ll << 31), "projection grid too large");
     const float qscale = 1.f / (g.vscale * F16x2::P_SCALE);           // powers of two: exact
-    hipLaunchKernelGGL(k1_pair_kernel<MT16>, dim3((unsigned)grid), dim3(512), 0, c->stream, d_v, (const _Float16*)d_phase,
-                       d_q, g.T, g.N_tot, g.A_pad / K1_BA, g.K, n_mblk, (int)n_tblk, g.vscale, qscale);
+    hipLaunchKernelGGL((k1_pair_kernel<MT16, GATHER>), dim3((unsigned)grid), dim3(512), 0, c->stream, d_v,
+                       (const _Float16*)d_phase, d_idx, d_q, g.T, g.N_tot, g.n_g, g.A_pad / K1_BA, g.K, n_mblk, (int)n_tblk,
+                       g.vscale, qscale);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
 }
@@ -349,12 +421,16 @@ static int launch_pair_variant(psa_ctx* c, const float* d_v, const void* d_phase
 // 128-row M blocks; 64-row blocks for k-lists of at most 32 (a one-block launch wastes nothing)
 int k1_pair_block_rows(int K) { return 2 * K <= 64 ? 64 : 128; }
 
-int launch_k1_pair(psa_ctx* c, const float* d_v, const void* d_phase, float2* d_q, const ProjGeom& g) {
+int launch_k1_pair(psa_ctx* c, const float* d_v, const void* d_phase, const int* d_idx, float2* d_q, const ProjGeom& g) {
     PSA_REQUIRE((g.m_blk == 128 || g.m_blk == 64) && g.M_pad % g.m_blk == 0, "projection kernel needs 64- or 128-row M blocks");
     PSA_REQUIRE(g.A_pad % (2 * K1_BA) == 0 && g.A_pad > 0, "projection kernel needs the atom axis padded to %d", 2 * K1_BA);
-    PSA_REQUIRE(g.n_g == g.N_tot && g.N_tot % 4 == 0, "projection kernel takes whole-trajectory groups, N %% 4 == 0");
     PSA_REQUIRE(g.vscale > 0.f, "f16 split kernel needs the array's scale");
-    return g.m_blk == 128 ? launch_pair_variant<4>(c, d_v, d_phase, d_q, g) : launch_pair_variant<2>(c, d_v, d_phase, d_q, g);
+    const bool contiguous = d_idx == nullptr && g.N_tot % 4 == 0 && g.n_g == g.N_tot;
+    if (g.m_blk == 128)
+        return contiguous ? launch_pair_variant<4, false>(c, d_v, d_phase, d_idx, d_q, g)
+                          : launch_pair_variant<4, true>(c, d_v, d_phase, d_idx, d_q, g);
+    return contiguous ? launch_pair_variant<2, false>(c, d_v, d_phase, d_idx, d_q, g)
+                      : launch_pair_variant<2, true>(c, d_v, d_phase, d_idx, d_q, g);
 }
 
 }  // namespace psa

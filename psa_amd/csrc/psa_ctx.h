@@ -194,9 +194,10 @@ int    k1_pair_atom_pad(int64_t n_g);
 int    k1_pair_block_rows(int K);
 float  k1_f16_vscale(unsigned absmax_bits);
 size_t pf16_table_bytes(int M_pad, int A_pad);
-int    launch_phase_table_f16(psa_ctx* c, const float* d_kvec, const float* d_mean_all, void* d_phase,
-                              const ProjGeom& g);
-int    launch_k1_pair(psa_ctx* c, const float* d_v, const void* d_phase, float2* d_q, const ProjGeom& g);
+int    launch_phase_table_f16(psa_ctx* c, const float* d_kvec, const float* d_mean_all, const int* d_idx,
+                              void* d_phase, const ProjGeom& g);
+int    launch_k1_pair(psa_ctx* c, const float* d_v, const void* d_phase, const int* d_idx, float2* d_q,
+                      const ProjGeom& g);
 
 // --- k2_epilogue.hip
 int launch_scale_transpose_c64(psa_ctx* c, const float2* d_slab, float2* d_out, int64_t T, int64_t K);

@@ -174,6 +174,30 @@ def test_shapes_against_oracle(engine, n_atoms, n_frames, n_k):
     assert not cx and not got.is_complex and rel_max(got.sed, ref) <= TOL
 
 
+@pytest.mark.parametrize("n_atoms,n_frames,n_k,idx", [
+    (128, 257, 24, None),                          # f16 kernel, 64-row M block, row DMA
+    (130, 257, 24, None),                          # ... per-atom gather DMA without an index list (N % 4 != 0)
+    (128, 257, 24, [5, 3, 3, 100, 77, 2] * 9),     # ... gather through an index list with duplicates
+    (132, 64, 17, None),                           # shortest k-list the f16 kernel takes
+    (130, 300, 50, None),                          # 128-row M block, gather without an index list
+    (256, 300, 50, list(range(0, 256, 3))),        # 128-row M block, index list
+    (192, 320, 200, None),                         # two 128-row M blocks, row DMA, several chains per group
+    (4096, 96, 40, None),                          # 128 stages: 16 fold periods
+])
+def test_f16_kernel_variants(engine, n_atoms, n_frames, n_k, idx):
+    """Every instantiation of k1_pair_kernel (row tiles per wavefront x row / gather DMA) against the
+    oracle, complex output."""
+    from psa_amd import SEDCalculator
+    tr = _random_traj(n_atoms, n_frames, seed=n_atoms + n_k)
+    calc = SEDCalculator(tr, 2, 2, 2).attach(engine=engine)
+    mags, vecs = calc.get_k_path([1, 0.3, 0.1], 3.0, n_k)
+    kw = {} if idx is None else {"basis_atom_indices": idx}
+    got = calc.calculate(mags, vecs, **kw)
+    ref, _, _ = O.calculate(tr.positions, tr.velocities, tr.types, tr.dt_ps, vecs, **kw)
+    assert rel_max(got.sed, ref) <= TOL
+    assert rel_max(got.intensity, O.intensity(ref)) <= TOL
+
+
 @pytest.mark.parametrize("n_atoms, n_k", [(300, 37), (1024, 100), (512, 9)])
 def test_kernels_agree_with_each_other(engine, n_atoms, n_k):
     """Split-precision (3 x bf16) tile kernel vs exact-fp32 MFMA kernel vs the shuffle kernel:
