@@ -150,8 +150,29 @@ int slot_absmax(psa_ctx* c, int slot) {
     return PSA_OK;
 }
 
-int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, const int* d_idx, bool disp,
-              ProjGeom* g) {
+// largest magnitude among the atoms of an index list: the maximum over the 32-atom column blocks
+// they sit in (one HBM pass per upload, then a host loop over the list)
+int group_absmax(psa_ctx* c, int slot, const int32_t* h_idx, int64_t n_g, unsigned* bits) {
+    DataSlot& s = c->slot[slot];
+    if (!s.blocks_known) {
+        const size_t n_blocks = (size_t)((s.N + 31) / 32);
+        PSA_TRY(c->d_absmax.reserve(n_blocks * sizeof(unsigned)));
+        PSA_TRY(launch_absmax_blocks(c, s.buf.as<float>(), s.T, s.N, c->d_absmax.as<unsigned>()));
+        s.block_absmax.resize(n_blocks);
+        PSA_HIP_CHECK(hipMemcpyAsync(s.block_absmax.data(), c->d_absmax.ptr, n_blocks * sizeof(unsigned),
+                                     hipMemcpyDeviceToHost, c->stream));
+        PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        s.blocks_known = true;
+    }
+    unsigned m = 0;
+    for (int64_t i = 0; i < n_g; ++i) m = std::max(m, s.block_absmax[(size_t)h_idx[i] >> 5]);
+    *bits = m;
+    return PSA_OK;
+}
+
+// h_idx: the group's index list on the host (nullptr: all atoms in order)
+int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, const int* d_idx, const int32_t* h_idx,
+              bool disp, ProjGeom* g) {
     g->T = c->slot[slot].T;
     g->N_tot = c->slot[slot].N;
     PSA_REQUIRE(n_g < (1ll << 30) && K_local < (1ll << 29), "group or k-list too large");
@@ -164,8 +185,14 @@ int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, const int* d_i
     g->split = 0;
     const bool autosel = c->k1_selector == PSA_K1_AUTO;
     if (autosel && k1_pair_eligible(d_idx, g->N_tot, n_g, K_local, disp)) {
-        PSA_TRY(slot_absmax(c, slot));
-        g->vscale = k1_f16_vscale(c->slot[slot].absmax_bits);
+        unsigned bits = 0;
+        if (h_idx) {
+            PSA_TRY(group_absmax(c, slot, h_idx, n_g, &bits));
+        } else {
+            PSA_TRY(slot_absmax(c, slot));
+            bits = c->slot[slot].absmax_bits;
+        }
+        g->vscale = k1_f16_vscale(bits);
         if (g->vscale > 0.f) g->split = 2;
     }
     if (g->split == 0 && (autosel || c->k1_selector == PSA_K1_SPLIT_BF16) &&
@@ -349,6 +376,7 @@ int psa_data_alloc(psa_ctx* c, int slot, int64_t T, int64_t N) {
     DataSlot& s = c->slot[slot];
     s.valid = false;
     s.absmax_known = false;
+    s.blocks_known = false;
     // 1 KiB of zeros behind the array: the split projection kernels pad the atom axis (to 32 atoms,
     // 64 in k1_pair.hip) and read up to 63 atoms past the final row, multiplied by zero phase columns
     const size_t bytes = (size_t)T * N * 3 * sizeof(float);
@@ -422,6 +450,7 @@ int psa_data_fill_synthetic(psa_ctx* c, int slot, uint64_t seed, int n_modes, co
         PSA_REQUIRE(amp && mode_comp && ct && st && ca && sa, "null mode table");
     const int64_t T = c->slot[slot].T, N = c->slot[slot].N;
     c->slot[slot].absmax_known = false;
+    c->slot[slot].blocks_known = false;
     // one packed upload: amp | comp | ct | st | ca | sa
     const size_t nm = (size_t)n_modes;
     const size_t o_amp = 0, o_comp = o_amp + nm * 4, o_ct = o_comp + nm * 4, o_st = o_ct + nm * T * 4,
@@ -506,7 +535,7 @@ int psa_sed_project(psa_ctx* c, int slot, const float* mean_pos_all, const float
         if (n_g == 0) continue;                                   // sed_calculator.py:64-65, 319-321
         const int* d_idx = group_idx ? c->d_idx.as<int>() + group_off[gi] : nullptr;
         ProjGeom g;
-        PSA_TRY(make_geom(c, slot, K_local, n_g, d_idx, disp, &g));
+        PSA_TRY(make_geom(c, slot, K_local, n_g, d_idx, group_idx ? group_idx + group_off[gi] : nullptr, disp, &g));
         PSA_TRY(project_group(c, slot, d_idx, g, disp, d_q));
         {
             StageTimer st(c, PSA_T_FFT);
@@ -715,7 +744,7 @@ int psa_debug_project_only(psa_ctx* c, int slot, const float* mean_pos_all, cons
     PSA_TRY(upload(c, c->d_mean_all, mean_pos_all, (size_t)N * 3 * sizeof(float)));
     if (idx) PSA_TRY(upload(c, c->d_idx, idx, (size_t)n_g * sizeof(int32_t)));
     ProjGeom g;
-    PSA_TRY(make_geom(c, slot, K, n_g, idx ? c->d_idx.as<int>() : nullptr, (flags & PSA_F_DISPLACEMENTS) != 0, &g));
+    PSA_TRY(make_geom(c, slot, K, n_g, idx ? c->d_idx.as<int>() : nullptr, idx, (flags & PSA_F_DISPLACEMENTS) != 0, &g));
     const size_t bytes = (size_t)K * 3 * T * sizeof(float2);
     PSA_TRY(c->d_qwork.reserve(bytes));
     PSA_TRY(project_group(c, slot, idx ? c->d_idx.as<int>() : nullptr, g,

@@ -86,6 +86,9 @@ struct DataSlot {
     // largest |x| of the array (float bits), computed on first use after the contents change
     bool     absmax_known = false;
     unsigned absmax_bits = 0;
+    // ... and per column block of 32 atoms (host copy), for index-list groups
+    bool                  blocks_known = false;
+    std::vector<unsigned> block_absmax;
 };
 
 // stage timing: event pairs recorded on the context's stream, resolved lazily
@@ -171,6 +174,7 @@ int launch_fill_synthetic(psa_ctx* c, float* d_v, int64_t T, int64_t N, uint64_t
                           const float* d_st, const float* d_ca, const float* d_sa);
 int launch_mean_over_frames(psa_ctx* c, const float* d_x, int64_t T, int64_t N, float* d_mean);
 int launch_absmax_bits(psa_ctx* c, const float* d_x, int64_t n, unsigned* d_out);
+int launch_absmax_blocks(psa_ctx* c, const float* d_x, int64_t T, int64_t N, unsigned* d_out);
 
 // --- k1_mfma.hip / k1_wave.hip
 int  k1_mfma_block_rows(int K);                    // M block of the variant chosen for K

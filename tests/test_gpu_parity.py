@@ -198,6 +198,58 @@ def test_f16_kernel_variants(engine, n_atoms, n_frames, n_k, idx):
     assert rel_max(got.intensity, O.intensity(ref)) <= TOL
 
 
+def test_f16_kernel_is_exactly_scale_invariant(engine):
+    """The f16 kernel rescales the data by a power of two taken from its largest magnitude and
+    undoes it exactly: multiplying the trajectory by 2^+-40 multiplies the result by exactly that."""
+    from psa_amd import SEDCalculator
+    base = _random_traj(256, 192, seed=5)
+    calc = SEDCalculator(base, 2, 2, 2).attach(engine=engine)
+    mags, vecs = calc.get_k_path("xyz", 2.0, 40)
+    ref = calc.calculate(mags, vecs).sed
+    for e in (-40, 40):
+        tr = _random_traj(256, 192, seed=5)
+        tr.velocities = (tr.velocities * np.float32(2.0 ** e)).astype(np.float32)
+        got = SEDCalculator(tr, 2, 2, 2).attach(engine=engine).calculate(mags, vecs).sed
+        assert np.array_equal(got, ref * np.complex64(2.0 ** e))
+
+
+def test_f16_kernel_wide_dynamic_range(engine):
+    """One atom 1e5 times faster than the rest, a third of the atoms 1e-4 times slower: every class
+    still contributes at float32 accuracy (the scale is set by the outlier)."""
+    from psa_amd import SEDCalculator
+    tr = _random_traj(384, 160, seed=8)
+    v = tr.velocities.copy()
+    v[:, 7, :] *= 1e5
+    v[:, 100:228, :] *= 1e-4
+    tr.velocities = v
+    calc = SEDCalculator(tr, 2, 2, 2).attach(engine=engine)
+    mags, vecs = calc.get_k_path([1, 0.3, 0.1], 3.0, 48)
+    for idx in (None, list(range(100, 228)), [i for i in range(384) if i != 7]):
+        kw = {} if idx is None else {"basis_atom_indices": idx}
+        got = calc.calculate(mags, vecs, **kw)
+        ref, _, _ = O.calculate(tr.positions, tr.velocities, tr.types, tr.dt_ps, vecs, **kw)
+        assert rel_max(got.sed, ref) <= TOL
+
+
+def test_non_finite_data_takes_the_bf16_kernel(engine):
+    """NaN / Inf in the array: no scale exists, the kernel that needs none runs, and the non-finite
+    values propagate to every output that depends on them, as in the reference."""
+    from psa_amd import SEDCalculator
+    tr = _random_traj(128, 96, seed=3)
+    v = tr.velocities.copy()
+    v[10, 5, 1] = np.inf
+    v[20, 6, 2] = np.nan
+    tr.velocities = v
+    calc = SEDCalculator(tr, 2, 2, 2).attach(engine=engine)
+    mags, vecs = calc.get_k_path("x", 1.0, 24)
+    got = calc.calculate(mags, vecs).sed
+    with np.errstate(all="ignore"):
+        ref, _, _ = O.calculate(tr.positions, tr.velocities, tr.types, tr.dt_ps, vecs)
+    assert not np.isfinite(got[:, :, 1]).any() and not np.isfinite(got[:, :, 2]).any()      # FFT spreads them
+    assert np.array_equal(np.isfinite(got), np.isfinite(ref))
+    assert rel_max(got[:, :, 0], ref[:, :, 0]) <= TOL
+
+
 @pytest.mark.parametrize("n_atoms, n_k", [(300, 37), (1024, 100), (512, 9)])
 def test_kernels_agree_with_each_other(engine, n_atoms, n_k):
     """Split-precision (3 x bf16) tile kernel vs exact-fp32 MFMA kernel vs the shuffle kernel:
