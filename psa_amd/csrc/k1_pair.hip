@@ -45,7 +45,9 @@ struct K1qCfg {
     static constexpr int M_BLK = 32 * MT16;        // two row halves
     static constexpr int T_BLK = 64;               // four frame groups of 16
     static constexpr int FOLD = 8;                 // stages per MFMA chain
-    static constexpr int RING = 3;                 // slots: stage s+1 being read, s+2 and s+3 in flight
+    // LDS slots: stage s+1 being read, s+2 .. s+RING in flight (a fourth slot for the HBM-bound
+    // 64-row variant measured no gain: 4.87 vs 4.84 ms)
+    static constexpr int RING = 3;
     static constexpr int P_STAGE_BYTES = F16x2::NP * M_BLK * K1_BA * 2;    // 16 KiB
     static constexpr int P_DMA = P_STAGE_BYTES / 1024 / 8;                 // pieces per wavefront: 2 (or 1)
     // V image of a frame group.  Whole trajectory: 16 rows x 384 B in 6 pieces of 1 KiB.  Gathered:
@@ -59,8 +61,9 @@ struct K1qCfg {
     static constexpr int RAW_STAGE_BYTES = 4 * RAW_GROUP_BYTES;
     static constexpr int STAGE_BYTES = P_STAGE_BYTES + RAW_STAGE_BYTES;    // 40 (32) KiB; gathered 48.5 (40.5)
     // gathered: a private ring of index rows (64 lanes x 4 B) per wavefront behind the stage slots
+    static constexpr int IDX_RING = 3;
     static constexpr int IDX_BASE = RING * STAGE_BYTES;
-    static constexpr int LDS_BYTES = IDX_BASE + (GATHER ? 8 * RING * 256 : 0);
+    static constexpr int LDS_BYTES = IDX_BASE + (GATHER ? 8 * IDX_RING * 256 : 0);
     static constexpr int BATCH = P_DMA + V_DMA + (GATHER ? 1 : 0);    // VMEM instructions per stage and wavefront
     static constexpr int RAWN = GATHER ? 8 : 6;    // 16-byte reads per lane and stage
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -153,7 +156,7 @@ k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, con
         int pos = (st < last ? st : last) * K1_BA + (lane & 31);
         return pos < n_g ? pos : n_g - 1;
     };
-    const unsigned idx_ring = lds0 + C::IDX_BASE + w * (C::RING * 256);
+    const unsigned idx_ring = lds0 + C::IDX_BASE + w * (C::IDX_RING * 256);
     // this wavefront's BATCH for stage st (clamped) -> slot: P' pieces first, then V (gathered: with
     // the atom index `atom`), then the index row of stage st + 2
     auto dma_stage = [&](int st, int slot, int atom) {
@@ -171,14 +174,14 @@ k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, con
         if constexpr (GATHER) {
             const int* src = idx ? idx + pos_of(st + 2) : nullptr;
             // no index list (N % 4 != 0): the "index" is the position itself; keep the DMA count uniform
-            lds_dma4(idx ? (const void*)src : (const void*)(V + (lane & 31)), idx_ring + ((st + 2) % C::RING) * 256);
+            lds_dma4(idx ? (const void*)src : (const void*)(V + (lane & 31)), idx_ring + ((st + 2) % C::IDX_RING) * 256);
         }
     };
     auto atom_from_ring = [&](int st) -> int {       // index of this lane's atom at stage st
         if constexpr (!GATHER) return 0;
         if (!idx) return pos_of(st);
         return *reinterpret_cast<const __attribute__((address_space(3))) int*>(
-            (const lds_u8*)(size_t)(idx_ring + (st % C::RING) * 256 + 4 * lane));
+            (const lds_u8*)(size_t)(idx_ring + (st % C::IDX_RING) * 256 + 4 * lane));
     };
 
     // ---- LDS read addresses ---------------------------------------------------------------------
@@ -211,28 +214,27 @@ k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, con
             lo[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
-    // ---- prologue: stages 0, 1, 2 in flight; stage 0 into registers ------------------------------
+    // ---- prologue: stages 0 .. RING-1 in flight; stage 0 into registers --------------------------
     {
-        // gathered: the first three index rows come straight from HBM (plain loads, before any DMA);
-        // the batches of stages 0, 1, 2 carry the index rows of stages 2, 3, 4 (row 2 is not used)
-        int a0 = 0, a1 = 0, a2 = 0;
-        if constexpr (GATHER) {
-            a0 = idx ? idx[pos_of(0)] : pos_of(0);
-            a1 = idx ? idx[pos_of(1)] : pos_of(1);
-            a2 = idx ? idx[pos_of(2)] : pos_of(2);
+        // gathered: the first index rows come straight from HBM (plain loads, before any DMA); the
+        // batch of stage k carries the index row of stage k + 2
+        int a0[C::RING];
+#pragma unroll
+        for (int k = 0; k < C::RING; ++k) {
+            a0[k] = 0;
+            if constexpr (GATHER) a0[k] = idx ? idx[pos_of(k)] : pos_of(k);
         }
-        dma_stage(0, 0, a0);
-        dma_stage(1, 1, a1);
-        dma_stage(2, 2, a2);
+#pragma unroll
+        for (int k = 0; k < C::RING; ++k) dma_stage(k, k, a0[k]);
     }
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * C::BATCH) : "memory");      // stage 0 landed
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((C::RING - 1) * C::BATCH) : "memory");      // stage 0 landed
     read_raw(0);
 #pragma unroll
     for (int mt = 0; mt < MT16; ++mt) read_a_tile(mt, 0);
     split_component<0>(raw, vscale, bs[0][0]);
     split_component<1>(raw, vscale, bs[0][1]);
     split_component<2>(raw, vscale, bs[0][2]);
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(C::BATCH) : "memory");   // stage 1 landed, slot 0 read
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((C::RING - 2) * C::BATCH) : "memory");   // stage 1 landed, slot 0 read
 
     // All products of one row tile; MFMAs that depend on one another are two instructions apart.
     auto mfma_tile = [&](int mt, int par, bool restart) {
@@ -250,8 +252,8 @@ k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, con
 #pragma unroll
         for (int c = 0; c < 3; ++c) hi[mt][c] = PR::mma(a[0][mt], bs[par][c][0], ch[c]);
     };
-    // One stage (slot = s % 3 holds stage s, already in registers; slot1 holds stage s+1, landed).
-    //   top: DMA of stage s+3 into slot (nobody reads it any more), V rows of stage s+1 read;
+    // One stage (slot = s % RING holds stage s, already in registers; slot1 holds stage s+1, landed).
+    //   top: DMA of stage s+RING into slot (nobody reads it any more), V rows of stage s+1 read;
     //   region mt: the tile's 9 MFMAs with a share of the split beside them, then its A fragments
     //   are refilled with those of stage s+1.  (Placing the DMA pieces between the regions, or half
     //   a stage apart in the two wavefronts of a SIMD, measured 3-5 % slower; a fourth slot that
@@ -259,10 +261,10 @@ k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, con
     auto stage = [&](auto par_c, auto restart_c, int s, int slot) {
         constexpr int  par = decltype(par_c)::value;
         constexpr bool restart = decltype(restart_c)::value;
-        const int      slot1 = slot == 2 ? 0 : slot + 1;
-        // gathered: the index row of stage s+3 came with the batch of stage s+1 (issued a stage ago,
-        // awaited at the end of it by the counted vmcnt)
-        if constexpr ((PSA_K1_EXPERIMENT & 1) == 0) dma_stage(s + 3, slot, atom_from_ring(s + 3));
+        const int      slot1 = slot == C::RING - 1 ? 0 : slot + 1;
+        // gathered: the index row of stage s+RING came with the batch issued two stages ago,
+        // awaited by the counted vmcnt at the end of the last stage
+        if constexpr ((PSA_K1_EXPERIMENT & 1) == 0) dma_stage(s + C::RING, slot, atom_from_ring(s + C::RING));
         read_raw(slot1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -286,14 +288,14 @@ k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, con
         // own pieces of stage s+2 landed (the batch just issued may stay in flight), own LDS reads
         // returned (the next stage's DMA overwrites the slot they read); then everyone's
         if constexpr ((PSA_K1_EXPERIMENT & 1) == 0)
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(C::BATCH) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((C::RING - 2) * C::BATCH) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    int slot = 0;                                      // s % 3
-    auto next_slot = [&]() { slot = slot == 2 ? 0 : slot + 1; };
+    int slot = 0;                                      // s % RING
+    auto next_slot = [&]() { slot = slot == C::RING - 1 ? 0 : slot + 1; };
     for (int s = 0; s < n_stage;) {                    // n_stage is even; a chain is an even number of stages
         const int len = n_stage - s < C::FOLD ? n_stage - s : C::FOLD;
         stage(I0{}, std::true_type{}, s, slot);
