@@ -99,6 +99,27 @@ def test_config3_projection_fft_and_parseval(engine, config3):
     np.testing.assert_allclose(lhs, rhs, rtol=2e-5)
 
 
+def test_config3_f16_kernel_before_the_fft(engine, config3):
+    """Full N = 32768: the "2 x f16" kernel's q (24 k-points -> 64-row blocks; 40 -> 128-row blocks),
+    sampled frames against float64.  This is where chain length shows: one MFMA chain over all 1024
+    stages was 1.4e-5 off at the coherent peak; folded every 8 stages it is as good as float32 BLAS."""
+    from psa_amd import synth
+    spec, r0, tables = config3["spec"], config3["r0"], config3["tables"]
+    T = spec.n_frames
+    for n_k in (24, 40):
+        pick = np.linspace(0, 255, n_k).round().astype(int)
+        vecs = config3["vecs"][pick]
+        q = engine.debug_project_only(0, r0, vecs)
+        phase = O.phase_table(vecs, r0)
+        for t0 in (0, 40000, T - 32):
+            block = synth.velocities_block(spec, tables, t0, 32)
+            ref = O.project_group(block, phase)
+            got = q[:, :, t0:t0 + 32].transpose(2, 0, 1)
+            exact = np.einsum("tac,ka->tkc", block.astype(np.float64), phase.astype(np.complex128))
+            assert rel_max(got, exact) < 3e-6 and rel_max(ref, exact) < 6e-6
+            assert rel_max(got, ref) < TOL
+
+
 def test_config3_planted_modes_and_shard_invariance(engine, config3):
     """All 256 k-points: the planted plane wave on the [110] path shows up as the known peak,
     and projecting the k-list in two shards (as two ranks would) changes nothing."""
