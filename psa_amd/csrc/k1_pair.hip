@@ -32,6 +32,7 @@
 // Timing experiments (tools/k1_experiments.sh builds side libraries with -DPSA_K1_EXPERIMENT=bits;
 // results are WRONG by construction, only the kernel time is of interest):
 //   1: no DMA in the main loop   2: no MFMAs (operands kept alive)   4: no split   8: no fold
+//  16: P' pieces re-read stage 0 (L2 hits)   32: V pieces re-read stage 0
 #ifndef PSA_K1_EXPERIMENT
 #define PSA_K1_EXPERIMENT 0
 #endif
@@ -45,8 +46,8 @@ struct K1qCfg {
     static constexpr int M_BLK = 32 * MT16;        // two row halves
     static constexpr int T_BLK = 64;               // four frame groups of 16
     static constexpr int FOLD = 8;                 // stages per MFMA chain
-    // LDS slots: stage s+1 being read, s+2 .. s+RING in flight (a fourth slot for the HBM-bound
-    // 64-row variant measured no gain: 4.87 vs 4.84 ms)
+    // LDS slots: stage s+1 being read, s+2 .. s+RING in flight (a fourth slot measured no gain:
+    // 4.87 vs 4.84 ms on the HBM-bound 64-row variant, 18.6 vs 18.6 ms on configuration 3)
     static constexpr int RING = 3;
     static constexpr int P_STAGE_BYTES = F16x2::NP * M_BLK * K1_BA * 2;    // 16 KiB
     static constexpr int P_DMA = P_STAGE_BYTES / 1024 / 8;                 // pieces per wavefront: 2 (or 1)
@@ -162,14 +163,15 @@ k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, con
     auto dma_stage = [&](int st, int slot, int atom) {
         const int      sc = st < last ? st : last;
         const unsigned dst = lds0 + slot * C::STAGE_BYTES;
+        const int      scp = (PSA_K1_EXPERIMENT & 16) ? 0 : sc, scv = (PSA_K1_EXPERIMENT & 32) ? 0 : sc;
 #pragma unroll
         for (int i = 0; i < C::P_DMA; ++i)
-            lds_dma16(pp + (size_t)sc * C::P_STAGE_BYTES + 1024 * i, dst + 1024 * (w * C::P_DMA + i));
+            lds_dma16(pp + (size_t)scp * C::P_STAGE_BYTES + 1024 * i, dst + 1024 * (w * C::P_DMA + i));
         const unsigned vdst = dst + C::P_STAGE_BYTES + wf * C::RAW_GROUP_BYTES + wh * C::V_DMA * C::V_PIECE_BYTES;
 #pragma unroll
         for (int j = 0; j < C::V_DMA; ++j) {
             if constexpr (GATHER) lds_dma12(vp[j] + 3 * (int64_t)atom, vdst + j * C::V_PIECE_BYTES);
-            else lds_dma16(vp[j] + (size_t)sc * K1_VROW, vdst + j * C::V_PIECE_BYTES);
+            else lds_dma16(vp[j] + (size_t)scv * K1_VROW, vdst + j * C::V_PIECE_BYTES);
         }
         if constexpr (GATHER) {
             const int* src = idx ? idx + pos_of(st + 2) : nullptr;

@@ -14,7 +14,7 @@ if [ "$mode" = build ]; then
   for x in "$@"; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I"$ROOT/include" -I"$SRC" -fno-fast-math \
       -ffp-contract=on -fno-slp-vectorize -DPSA_K1_EXPERIMENT=$x -c "$SRC/k1_pair.hip" -o "$OUT/k1_pair_x$x.o" 2>/dev/null
-    objs=$(ls "$SRC"/build/*.o | grep -v k1_pair.o)
+    objs=$(sed -n 's/^SRCS := //p' "$SRC/Makefile" | tr ' ' '\n' | grep -v k1_pair | sed "s#\(.*\)\.hip#$SRC/build/\1.o#")
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$OUT/libpsa_hip_x$x.so" $objs "$OUT/k1_pair_x$x.o" \
       -L/opt/rocm/lib -lrocfft -lrccl -Wl,-rpath,/opt/rocm/lib 2>/dev/null
     echo "built $OUT/libpsa_hip_x$x.so"
