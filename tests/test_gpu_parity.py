@@ -231,6 +231,28 @@ def test_f16_kernel_wide_dynamic_range(engine):
         assert rel_max(got.sed, ref) <= TOL
 
 
+def test_f16_kernel_linearity_and_atom_order(engine):
+    """Properties that need no reference: the complex SED is linear in the velocities, and summing
+    the atoms in another order (an index list that is a permutation -> the gather form of the kernel)
+    gives the row-DMA result to rounding."""
+    from psa_amd import SEDCalculator
+    tr1, tr2 = _random_traj(512, 256, seed=21), _random_traj(512, 256, seed=22)
+    tr2.positions = tr1.positions
+    mags, vecs = SEDCalculator(tr1, 2, 2, 2).get_k_path([1, 1, 0], 2.0, 64)
+
+    def run(vel, **kw):
+        tr = _random_traj(512, 256, seed=21)
+        tr.velocities = vel
+        return SEDCalculator(tr, 2, 2, 2).attach(engine=engine).calculate(mags, vecs, **kw).sed.astype(np.complex128)
+
+    s1, s2 = run(tr1.velocities), run(tr2.velocities)
+    both = run((np.float32(0.75) * tr1.velocities + tr2.velocities).astype(np.float32))
+    scale = np.abs(both).max()
+    assert np.abs(both - (0.75 * s1 + s2)).max() / scale < 2e-6
+    perm = np.random.default_rng(3).permutation(512)
+    assert np.abs(run(tr1.velocities, basis_atom_indices=perm) - s1).max() / np.abs(s1).max() < 2e-6
+
+
 def test_non_finite_data_takes_the_bf16_kernel(engine):
     """NaN / Inf in the array: no scale exists, the kernel that needs none runs, and the non-finite
     values propagate to every output that depends on them, as in the reference."""
