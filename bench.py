@@ -41,6 +41,10 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # ibid. :43 (dense bf16 MFMA)
 SPLIT_MFMA_FLOP_PER_UNIT = {"auto": 36, "bf16x3": 72}   # 16-bit products issued per fp32 product: 3 (2xf16) / 6 (3xbf16)
 PEAK_HBM_GBS = 8000.0             # ibid. :36 (spec; 6.29 TB/s measured copy)
 FLOP_PER_UNIT = 12                # 3 components x (re, im) x FMA per (k, t, atom)  
+# k-split model for N > 1 (measured on one MI355X; the link rate is an assumption)
+K1_UNITS_PER_S = 3.4e13           # slope of the f16 projection kernel's time over the k-count
+HBM_BOUND_K1_BPS = 5.3e12         # trajectory bytes per second of its HBM-bound small-K variant
+XGMI_LINK_BPS = 64e9              # one direction of one xGMI link
 
 
 def parse_args():
@@ -55,6 +59,8 @@ def parse_args():
     ap.add_argument("--k1", default="auto", choices=["auto", "bf16x3", "mfma32"],
                     help="projection kernel: auto = split-precision 2xf16 MFMA (product default), "
                          "bf16x3 = split-precision 3xbf16 MFMA, mfma32 = exact-fp32 MFMA")
+    ap.add_argument("--even-split", action="store_true",
+                    help="N > 1: give every rank the same number of k-points instead of the root-heavy split")
     ap.add_argument("--check", action="store_true",
                     help="after timing, rank 0 recomputes every k-point on its own GPU and compares the "
                          "gathered result with it (multi-rank plumbing check)")
@@ -159,6 +165,14 @@ def main():
     flags = _hip.F_INTENSITY if intensity_out else 0
     mean_pos = r0                         # mean of a static lattice; positions never leave the host
     n_sum_atoms = sum(len(g) for g in groups)
+    if world > 1 and not args.even_split:
+        # only rank 0 receives the result: it takes more k-vectors than the ranks that have to ship
+        # their rows to it (dist.root_heavy_counts).  Cost model from the one-GPU measurements in
+        # K1 time = max(one trajectory pass at the HBM-bound rate,
+        # 0.45 of that + n_k * atoms * frames / 3.4e13 units/s); one xGMI link per sender.
+        floor_s = 12.0 * n_sum_atoms * T / HBM_BOUND_K1_BPS
+        group.balance = dict(per_k_s=n_sum_atoms * T / K1_UNITS_PER_S, base_s=0.45 * floor_s, floor_s=floor_s,
+                             per_k_bytes=(4.0 if intensity_out else 24.0) * T, link_bytes_per_s=XGMI_LINK_BPS)
 
     def step():
         group.project(_hip.SLOT_VELOCITIES, mean_pos, vecs, dev_groups, flags)
@@ -240,7 +254,7 @@ def main():
                        "atoms": N, "timesteps": T, "k_points": K, "atom_groups": len(groups),
                        "output": "(T,K) float32 intensity" if intensity_out else "(T,K,3) complex64 + intensity",
                        "parallelism": (f"k-shard x{world} ({'RCCL' if group.transport == 'rccl' else 'HOST-STAGED (RCCL unavailable)'}"
-                                       f" gather to rank 0)") if world > 1 else "single GPU",
+                                       f" gather to rank 0; k-points per rank {group.ranges(K)[1].tolist()})") if world > 1 else "single GPU",
                        "device": info["name"]},
             "roofline": {"kernel": kernel_name, "bound": bound,
                          "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,

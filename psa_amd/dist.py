@@ -32,15 +32,45 @@ from . import _hip
 logger = logging.getLogger(__name__)
 
 
-def shard_ranges(n_k: int, nranks: int) -> Tuple[np.ndarray, np.ndarray]:
-    """Contiguous, balanced split of n_k rows: (offsets, counts), the first n_k % nranks
-    ranks take one extra row.  Ranks beyond n_k get empty ranges."""
+def shard_ranges(n_k: int, nranks: int, counts: Optional[Sequence[int]] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Contiguous split of n_k rows: (offsets, counts).  Default: balanced, the first
+    n_k % nranks ranks take one extra row, ranks beyond n_k get empty ranges.  `counts` gives the
+    rows per rank explicitly (see `root_heavy_counts`)."""
     if nranks < 1:
         raise ValueError("nranks must be >= 1")
-    base, extra = divmod(int(n_k), nranks)
-    counts = np.array([base + (1 if r < extra else 0) for r in range(nranks)], dtype=np.int64)
+    if counts is None:
+        base, extra = divmod(int(n_k), nranks)
+        counts = [base + (1 if r < extra else 0) for r in range(nranks)]
+    counts = np.asarray(counts, dtype=np.int64)
+    if counts.shape != (nranks,) or counts.min() < 0 or counts.sum() != n_k:
+        raise ValueError("counts must be one non-negative row count per rank adding up to n_k")
     offsets = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
     return offsets, counts
+
+
+def root_heavy_counts(n_k: int, nranks: int, root: int, per_k_s: float, base_s: float, floor_s: float,
+                      per_k_bytes: float, link_bytes_per_s: float) -> np.ndarray:
+    """Rows per rank when only `root` receives the result: the root sends nothing, every other rank
+    ships its rows over its own link after computing them, so the root takes more rows.  Model:
+    a rank with n rows computes for max(floor_s, base_s + per_k_s * n) (floor_s = one pass over
+    the trajectory at the HBM rate) and then sends for n * per_k_bytes / link_bytes_per_s; the
+    latest finishing time is minimised over the rows given to each non-root rank (never more than
+    the even share, which also wins ties)."""
+    if nranks == 1:
+        return np.array([n_k], dtype=np.int64)
+    send = per_k_bytes / link_bytes_per_s
+
+    def compute(n: int) -> float:
+        return max(floor_s, base_s + per_k_s * n) if n > 0 else 0.0
+
+    best, best_t = n_k // nranks, np.inf
+    for other in range(n_k // nranks, (0 if n_k < nranks else 1) - 1, -1):     # even share first: it wins ties
+        t = max(compute(n_k - other * (nranks - 1)), compute(other) + send * other)
+        if t < best_t * (1 - 1e-9):
+            best, best_t = other, t
+    counts = np.full(nranks, best, dtype=np.int64)
+    counts[root] = n_k - best * (nranks - 1)
+    return counts
 
 
 # --------------------------------------------------------------------------- exchanges
@@ -182,12 +212,17 @@ class KShardGroup:
     gather="root" : only rank `root` receives and returns the result, the others return None.
     """
 
-    def __init__(self, engine: "_hip.Engine", exchange: Exchange, gather: str = "all", root: int = 0):
+    def __init__(self, engine: "_hip.Engine", exchange: Exchange, gather: str = "all", root: int = 0,
+                 balance: Optional[dict] = None):
+        """balance (gather="root" only): keyword arguments of `root_heavy_counts` other than n_k,
+        nranks and root -- gives the root a larger block of k-vectors to offset the result rows
+        the other ranks have to ship to it."""
         if gather not in ("all", "root"):
             raise ValueError("gather must be 'all' or 'root'")
         self.engine, self.exchange = engine, exchange
         self.rank, self.nranks = exchange.rank, exchange.nranks
         self.gather_mode, self.root = gather, root
+        self.balance = balance if gather == "root" else None
         self.has_result = False
         self.transport = "rccl"
         if self.nranks > 1:
@@ -206,15 +241,21 @@ class KShardGroup:
                                "through the host rendezvous instead -- correct, but not the xGMI path",
                                errors[0].splitlines()[-1])
 
+    def ranges(self, n_k: int) -> Tuple[np.ndarray, np.ndarray]:
+        counts = None
+        if self.balance and self.nranks > 1:
+            counts = root_heavy_counts(n_k, self.nranks, self.root, **self.balance)
+        return shard_ranges(n_k, self.nranks, counts)
+
     def my_range(self, n_k: int) -> Tuple[int, int]:
-        off, cnt = shard_ranges(n_k, self.nranks)
+        off, cnt = self.ranges(n_k)
         return int(off[self.rank]), int(cnt[self.rank])
 
     def project(self, slot, mean_pos_all, k_vectors, groups, flags):
         """Project this rank's block of k-vectors and exchange slab rows.  Asynchronous on
         the engine's stream; no host sync."""
         n_k = len(k_vectors)
-        off, cnt = shard_ranges(n_k, self.nranks)
+        off, cnt = self.ranges(n_k)
         lo, n = int(off[self.rank]), int(cnt[self.rank])
         self.engine.project(slot, mean_pos_all, np.asarray(k_vectors)[lo:lo + n], groups, flags,
                             K_total=n_k, k_offset=lo)

@@ -35,7 +35,34 @@ def test_shard_ranges_partition(n_k, nranks):
         dist.shard_ranges(4, 0)
 
 
-def _sharded_worker(rank, world, port, backend, gather, results, no_rccl=False):
+MODEL = dict(per_k_s=1.0, base_s=0.5, floor_s=2.0, per_k_bytes=4.0, link_bytes_per_s=1.0)   # sending costs 4 per row
+
+
+@pytest.mark.parametrize("n_k, nranks, root", [(256, 2, 0), (256, 4, 0), (256, 8, 3), (7, 2, 0), (5, 8, 0), (0, 2, 1), (9, 1, 0)])
+def test_root_heavy_counts(n_k, nranks, root):
+    cnt = dist.root_heavy_counts(n_k, nranks, root, **MODEL)
+    off, cnt2 = dist.shard_ranges(n_k, nranks, cnt)
+    assert cnt.sum() == n_k and np.array_equal(cnt, cnt2) and cnt.min() >= 0
+    others = np.delete(cnt, root)
+    assert (others == others[0]).all() if nranks > 1 else True
+    if nranks > 1:
+        assert cnt[root] >= others[0]                     # the root never gets less than the others
+        even = n_k // nranks
+
+        def finish(c_root, c_other):
+            comp = lambda n: max(MODEL["floor_s"], MODEL["base_s"] + MODEL["per_k_s"] * n) if n else 0.0
+            return max(comp(c_root), comp(c_other) + 4.0 * c_other)
+        assert finish(cnt[root], others[0]) <= finish(n_k - even * (nranks - 1), even) + 1e-12
+    with pytest.raises(ValueError):
+        dist.shard_ranges(10, 2, [5, 4])
+
+
+def test_root_heavy_counts_with_free_links_is_the_even_split():
+    cnt = dist.root_heavy_counts(256, 4, 0, per_k_s=1.0, base_s=0.0, floor_s=0.0, per_k_bytes=0.0, link_bytes_per_s=1.0)
+    assert list(cnt) == [64, 64, 64, 64]
+
+
+def _sharded_worker(rank, world, port, backend, gather, results, no_rccl=False, balance=None):
     """One rank of a 2-process k-sharded `calculate` (oracle-backed engine)."""
     import numpy as np
     import conftest
@@ -71,7 +98,7 @@ def _sharded_worker(rank, world, port, backend, gather, results, no_rccl=False):
         d = {k: z[k] for k in z.files}
     d["dt_ps"], d["cells"] = float(d["dt_ps"]), tuple(int(v) for v in d["cells"])
     eng = ExchangeEngine(rank=rank)
-    group = D.KShardGroup(eng, ex, gather=gather, root=0)
+    group = D.KShardGroup(eng, ex, gather=gather, root=0, balance=balance)
     calc = conftest.make_calculator(d).attach(shard_group=group)
     mags, vecs = calc.get_k_path([1, 1, 0], 2.0, 7)               # 7 k-points over 2 ranks: 4 + 3
     out = {}
@@ -88,16 +115,17 @@ def _sharded_worker(rank, world, port, backend, gather, results, no_rccl=False):
         td.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend, gather, no_rccl", [("gloo", "all", False), ("gloo", "root", False),
-                                                      ("tcp", "all", False), ("gloo", "root", True)])
-def test_two_rank_sharded_calculate_equals_unsharded(backend, gather, no_rccl):
+@pytest.mark.parametrize("backend, gather, no_rccl, balance", [
+    ("gloo", "all", False, None), ("gloo", "root", False, None), ("tcp", "all", False, None),
+    ("gloo", "root", True, None), ("gloo", "root", False, MODEL), ("tcp", "all", False, MODEL)])
+def test_two_rank_sharded_calculate_equals_unsharded(backend, gather, no_rccl, balance):
     import conftest
     from oracle import psa_oracle as O
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         results = mgr.dict()
-        procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, backend, gather, results, no_rccl))
+        procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, backend, gather, results, no_rccl, balance))
                  for r in range(world)]
         for p in procs:
             p.start()
@@ -113,7 +141,10 @@ def test_two_rank_sharded_calculate_equals_unsharded(backend, gather, no_rccl):
     ref_c, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], float(d["dt_ps"]), vecs)
     ref_i, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], float(d["dt_ps"]), vecs,
                               basis_atom_types=[1, 2], summation_mode="incoherent")
-    assert res[0]["coh_range"] == (0, 4, 7) and res[1]["coh_range"] == (4, 3, 7)
+    if balance and gather == "root":                      # 7 rows, sending costs 4 per row: the root takes 6
+        assert res[0]["coh_range"] == (0, 6, 7) and res[1]["coh_range"] == (6, 1, 7)
+    else:                                                 # (gather="all" ignores the model)
+        assert res[0]["coh_range"] == (0, 4, 7) and res[1]["coh_range"] == (4, 3, 7)
     assert res[0]["transport"] == res[1]["transport"] == ("host" if no_rccl else "rccl")
     for rank in range(world):
         if gather == "root" and rank != 0:
