@@ -172,7 +172,8 @@ def main():
         # 0.45 of that + n_k * atoms * frames / 3.4e13 units/s); one xGMI link per sender.
         floor_s = 12.0 * n_sum_atoms * T / HBM_BOUND_K1_BPS
         group.balance = dict(per_k_s=n_sum_atoms * T / K1_UNITS_PER_S, base_s=0.45 * floor_s, floor_s=floor_s,
-                             per_k_bytes=(4.0 if intensity_out else 24.0) * T, link_bytes_per_s=XGMI_LINK_BPS)
+                             per_k_bytes=(4.0 if intensity_out else 24.0) * T, link_bytes_per_s=XGMI_LINK_BPS,
+                             block_k=64)          # 128-row M blocks of the projection kernel
 
     def step():
         group.project(_hip.SLOT_VELOCITIES, mean_pos, vecs, dev_groups, flags)

@@ -49,11 +49,13 @@ def shard_ranges(n_k: int, nranks: int, counts: Optional[Sequence[int]] = None) 
 
 
 def root_heavy_counts(n_k: int, nranks: int, root: int, per_k_s: float, base_s: float, floor_s: float,
-                      per_k_bytes: float, link_bytes_per_s: float) -> np.ndarray:
+                      per_k_bytes: float, link_bytes_per_s: float, block_k: int = 1) -> np.ndarray:
     """Rows per rank when only `root` receives the result: the root sends nothing, every other rank
     ships its rows over its own link after computing them, so the root takes more rows.  Model:
-    a rank with n rows computes for max(floor_s, base_s + per_k_s * n) (floor_s = one pass over
-    the trajectory at the HBM rate) and then sends for n * per_k_bytes / link_bytes_per_s; the
+    a rank with n rows computes for max(floor_s, base_s + per_k_s * n') (floor_s = one pass over
+    the trajectory at the HBM rate; n' = n rounded up to the projection kernel's block of block_k
+    k-vectors, half a block for the short-list variant) and then sends for
+    n * per_k_bytes / link_bytes_per_s; the
     latest finishing time is minimised over the rows given to each non-root rank (never more than
     the even share, which also wins ties)."""
     if nranks == 1:
@@ -61,7 +63,10 @@ def root_heavy_counts(n_k: int, nranks: int, root: int, per_k_s: float, base_s: 
     send = per_k_bytes / link_bytes_per_s
 
     def compute(n: int) -> float:
-        return max(floor_s, base_s + per_k_s * n) if n > 0 else 0.0
+        if n <= 0:
+            return 0.0
+        padded = n if block_k <= 1 else (block_k // 2 if 2 * n <= block_k else -(-n // block_k) * block_k)
+        return max(floor_s, base_s + per_k_s * padded)
 
     best, best_t = n_k // nranks, np.inf
     for other in range(n_k // nranks, (0 if n_k < nranks else 1) - 1, -1):     # even share first: it wins ties
