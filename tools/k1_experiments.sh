@@ -2,7 +2,8 @@
 # Build side copies of libpsa_hip.so with timing experiments compiled into the large-K projection
 # kernel (see PSA_K1_EXPERIMENT in psa_amd/csrc/k1_pair.hip) and time configuration 3 with each:
 #   tools/k1_experiments.sh build 1 2 4 ...      (in the build container)
-#   tools/k1_experiments.sh run 1 2 4 ...        (on the GPU box; writes gpurun_out/k1_experiments.txt)
+#   tools/k1_experiments.sh run 1 2 4 ...        (on the GPU box; writes gpurun_out/k1_experiments.txt;
+#                                                 BENCH_ARGS="--k-points 32" selects another workload)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/psa_amd/csrc
@@ -25,7 +26,7 @@ else
   for x in "$@"; do
     lib=$SRC/libpsa_hip.so
     [ "$x" != 0 ] && lib=$OUT/libpsa_hip_x$x.so
-    PSA_HIP_LIBRARY=$lib python "$ROOT/bench.py" --no-cpu-baseline --steps 5 --warmup 1 2>/dev/null |
+    PSA_HIP_LIBRARY=$lib python "$ROOT/bench.py" --no-cpu-baseline --steps 5 --warmup 1 $BENCH_ARGS 2>/dev/null |
       python -c "import json,sys; d=json.loads(sys.stdin.read()); print('experiment $x: K1', round(d['roofline']['avg_launch_ms'],3), 'ms')" \
       | tee -a "$ROOT/gpurun_out/k1_experiments.txt"
   done
