@@ -34,6 +34,8 @@ SIGNATURES = {
     "psa_abi_version": (C.c_int, []),
     "psa_last_error": (C.c_char_p, []),
     "psa_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "psa_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "psa_host_free": (C.c_int, [C.c_void_p]),
     "psa_create": (C.c_int, [C.c_int, C.POINTER(_ctx)]),
     "psa_destroy": (C.c_int, [_ctx]),
     "psa_synchronize": (C.c_int, [_ctx]),
@@ -133,6 +135,74 @@ def pack_groups(groups: Optional[Sequence[np.ndarray]]):
     if idx.size and (idx.min() < 0 or idx.max() >= 2 ** 31):
         raise ValueError("Atom indices in basis out of bounds.")
     return np.ascontiguousarray(idx, dtype=np.int32), off, len(groups)
+
+
+class _PinnedPool:
+    """Page-locked host buffers for result arrays, recycled by size.  A buffer goes back to the pool
+    when the last NumPy view of it is garbage-collected; at most `keep_bytes` idle bytes are kept."""
+
+    granule = 2 << 20
+    min_bytes = 1 << 20                     # smaller results: ordinary memory
+    keep_bytes = 4 << 30                    # idle buffers kept for reuse
+    max_live_bytes = 16 << 30               # page-locked bytes handed out and not yet collected: beyond
+                                            # this, results go to ordinary memory
+
+    def __init__(self):
+        self._idle = {}                     # size -> [address, ...]
+        self._idle_bytes = 0
+        self._live_bytes = 0
+        self._lock = threading.Lock()
+
+    def _give_back(self, address: int, size: int):
+        with self._lock:
+            self._live_bytes -= size
+            if self._idle_bytes + size <= self.keep_bytes:
+                self._idle.setdefault(size, []).append(address)
+                self._idle_bytes += size
+                return
+        load_library().psa_host_free(C.c_void_p(address))
+
+    def empty(self, shape, dtype) -> np.ndarray:
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if nbytes < self.min_bytes:
+            return np.empty(shape, dtype)
+        size = -(-nbytes // self.granule) * self.granule
+        with self._lock:
+            if self._live_bytes + size > self.max_live_bytes:
+                return np.empty(shape, dtype)
+            self._live_bytes += size
+            stack = self._idle.get(size)
+            address = stack.pop() if stack else None
+            if address is not None:
+                self._idle_bytes -= size
+        if address is None:
+            p = C.c_void_p()
+            try:
+                _check(load_library().psa_host_alloc(size, C.byref(p)), "psa_host_alloc")
+            except PsaHipError:             # e.g. the locked-memory limit: an ordinary array will do
+                with self._lock:
+                    self._live_bytes -= size
+                return np.empty(shape, dtype)
+            address = p.value
+        block = (C.c_char * size).from_address(address)
+        weakref.finalize(block, self._give_back, address, size)     # block dies with its last view
+        return np.frombuffer(block, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
+
+    def drain(self):
+        with self._lock:
+            idle, self._idle, self._idle_bytes = self._idle, {}, 0
+        for stack in idle.values():
+            for address in stack:
+                load_library().psa_host_free(C.c_void_p(address))
+
+
+_pinned_pool = _PinnedPool()
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """np.empty in page-locked memory (results of at least 1 MiB); an ordinary writable ndarray."""
+    return _pinned_pool.empty(shape, dtype)
 
 
 class Engine:
@@ -255,7 +325,7 @@ class Engine:
         if not fetch:
             _check(self._lib.psa_sed_finalize(self._h, None), "psa_sed_finalize")
             return None
-        out = (np.empty((T, K), np.float32) if intensity else np.empty((T, K, 3), np.complex64))
+        out = pinned_empty((T, K), np.float32) if intensity else pinned_empty((T, K, 3), np.complex64)
         _check(self._lib.psa_sed_finalize(self._h, out.ctypes.data_as(C.c_void_p)),
                "psa_sed_finalize")
         return out

@@ -284,6 +284,17 @@ int psa_device_count(int* count) {
     return PSA_OK;
 }
 
+int psa_host_alloc(size_t bytes, void** out) {
+    PSA_REQUIRE(out != nullptr && bytes > 0, "bad argument");
+    PSA_HIP_CHECK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return PSA_OK;
+}
+
+int psa_host_free(void* p) {
+    if (p) PSA_HIP_CHECK(hipHostFree(p));
+    return PSA_OK;
+}
+
 int psa_create(int device, psa_ctx** out) {
     PSA_REQUIRE(out != nullptr, "null out");
     int n = 0;

@@ -440,3 +440,28 @@ def test_calculate_from_worker_threads(engine, trajs):
     for i in range(2):
         ref, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], d["dt_ps"], ks[i][1])
         assert out[i].shape == ref.shape and rel_max(out[i], ref) <= TOL
+
+
+def test_results_come_in_recycled_page_locked_memory(engine, trajs):
+    """Results of 1 MiB and more are ordinary writable ndarrays on page-locked host memory; the block
+    returns to the pool when its last view dies and is handed out again."""
+    import gc
+    from psa_amd import _hip
+    calc = _calc(trajs["a"], engine)
+    mags, vecs = calc.get_k_path("x", 1.0, 400)                     # (128, 400, 3) complex64 = 1.2 MB
+    sed = calc.calculate(mags, vecs).sed
+    assert sed.flags.writeable and sed.flags.c_contiguous and sed.dtype == np.complex64
+    ref, _, _ = O.calculate(trajs["a"]["positions"], trajs["a"]["velocities"], trajs["a"]["types"],
+                            trajs["a"]["dt_ps"], vecs)
+    assert rel_max(sed, ref) <= TOL
+    address, view = sed.ctypes.data, sed[3:5]
+    del sed
+    gc.collect()
+    assert address not in sum(_hip._pinned_pool._idle.values(), [])   # a view still holds the block
+    del view
+    gc.collect()
+    assert address in sum(_hip._pinned_pool._idle.values(), [])
+    again = calc.calculate(mags, vecs).sed
+    assert again.ctypes.data == address and rel_max(again, ref) <= TOL
+    small = calc.calculate(mags[:4], vecs[:4]).sed                   # 12 KB: ordinary memory
+    assert small.ctypes.data not in sum(_hip._pinned_pool._idle.values(), [])
