@@ -346,12 +346,12 @@ class Engine:
                "psa_slab_write")
 
     def result_intensity(self, T: int, K: int) -> np.ndarray:
-        out = np.empty((T, K), np.float32)
+        out = pinned_empty((T, K), np.float32)
         _check(self._lib.psa_result_intensity(self._h, _f32(out)), "psa_result_intensity")
         return out
 
     def result_chiral_phase(self, T: int, K: int, c1: int, c2: int) -> np.ndarray:
-        out = np.empty((T, K), np.float32)
+        out = pinned_empty((T, K), np.float32)
         _check(self._lib.psa_result_chiral_phase(self._h, c1, c2, _f32(out)),
                "psa_result_chiral_phase")
         return out
