@@ -388,6 +388,7 @@ int psa_data_alloc(psa_ctx* c, int slot, int64_t T, int64_t N) {
     s.valid = false;
     s.absmax_known = false;
     s.blocks_known = false;
+    ++s.generation;
     // 1 KiB of zeros behind the array: the split projection kernels pad the atom axis (to 32 atoms,
     // 64 in k1_pair.hip) and read up to 63 atoms past the final row, multiplied by zero phase columns
     const size_t bytes = (size_t)T * N * 3 * sizeof(float);
@@ -438,6 +439,11 @@ int psa_data_release(psa_ctx* c, int slot) {
     c->slot[slot].buf.release();
     c->slot[slot].valid = false;
     c->slot[slot].T = c->slot[slot].N = 0;
+    ++c->slot[slot].generation;
+    if (slot == PSA_SLOT_POSITIONS) {                      // the displacements derived from it go too
+        c->slot[PSA_NUM_SLOTS].buf.release();
+        c->slot[PSA_NUM_SLOTS].valid = false;
+    }
     return PSA_OK;
 }
 
@@ -462,6 +468,7 @@ int psa_data_fill_synthetic(psa_ctx* c, int slot, uint64_t seed, int n_modes, co
     const int64_t T = c->slot[slot].T, N = c->slot[slot].N;
     c->slot[slot].absmax_known = false;
     c->slot[slot].blocks_known = false;
+    ++c->slot[slot].generation;
     // one packed upload: amp | comp | ct | st | ca | sa
     const size_t nm = (size_t)n_modes;
     const size_t o_amp = 0, o_comp = o_amp + nm * 4, o_ct = o_comp + nm * 4, o_st = o_ct + nm * T * 4,
@@ -498,6 +505,40 @@ int psa_mean_positions(psa_ctx* c, int slot, float* mean_host) {
     return PSA_OK;
 }
 
+// Displacement mode on the fast kernels: positions - mean as an array of its own (what the reference
+// builds as a temporary, sed_calculator.py:70-72), cached while positions and mean stay the same.
+// *slot_io becomes the internal slot and *disp false; if HBM has no room for the second array the
+// call proceeds with the subtract-while-staging float32 kernel.
+int materialise_displacements(psa_ctx* c, int* slot_io, bool* disp, const float* mean_host) {
+    if (!*disp || c->k1_selector == PSA_K1_MFMA32 || c->k1_selector == PSA_K1_WAVE) return PSA_OK;
+    DataSlot&       src = c->slot[*slot_io];
+    DataSlot&       dst = c->slot[PSA_NUM_SLOTS];
+    const size_t    n_mean = (size_t)src.N * 3;
+    const bool fresh = dst.valid && c->disp_source == src.generation && dst.T == src.T && dst.N == src.N &&
+                       c->disp_mean.size() == n_mean &&
+                       std::memcmp(c->disp_mean.data(), mean_host, n_mean * sizeof(float)) == 0;
+    if (!fresh) {
+        const size_t bytes = (size_t)src.T * src.N * 3 * sizeof(float);
+        dst.valid = false;
+        if (dst.buf.reserve(bytes + 1024) != PSA_OK) {          // no room: keep the float32 path
+            (void)hipGetLastError();
+            return PSA_OK;
+        }
+        PSA_HIP_CHECK(hipMemsetAsync((char*)dst.buf.ptr + bytes, 0, 1024, c->stream));
+        PSA_TRY(launch_subtract_mean(c, src.buf.as<float>(), c->d_mean_all.as<float>(), dst.buf.as<float>(), src.T, src.N));
+        dst.T = src.T;
+        dst.N = src.N;
+        dst.valid = true;
+        dst.absmax_known = dst.blocks_known = false;
+        ++dst.generation;
+        c->disp_mean.assign(mean_host, mean_host + n_mean);
+        c->disp_source = src.generation;
+    }
+    *slot_io = PSA_NUM_SLOTS;
+    *disp = false;
+    return PSA_OK;
+}
+
 // ---- the hot path ---------------------------------------------------------------
 int psa_sed_project(psa_ctx* c, int slot, const float* mean_pos_all, const float* k_vectors,
                     int64_t K_local, int64_t K_total, int64_t k_offset, const int32_t* group_idx,
@@ -507,7 +548,7 @@ int psa_sed_project(psa_ctx* c, int slot, const float* mean_pos_all, const float
     PSA_TRY(check_slot(c, slot));
     const int64_t T = c->slot[slot].T, N = c->slot[slot].N;
     const bool intensity = (flags & PSA_F_INTENSITY) != 0;
-    const bool disp = (flags & PSA_F_DISPLACEMENTS) != 0;
+    bool       disp = (flags & PSA_F_DISPLACEMENTS) != 0;
     PSA_REQUIRE(mean_pos_all != nullptr, "null mean_pos_all");
     PSA_REQUIRE(K_local >= 0 && K_total >= 1 && k_offset >= 0 && k_offset + K_local <= K_total,
                 "k range [%lld,%lld) outside [0,%lld)", (long long)k_offset,
@@ -533,6 +574,7 @@ int psa_sed_project(psa_ctx* c, int slot, const float* mean_pos_all, const float
         if (group_idx)
             PSA_TRY(upload(c, c->d_idx, group_idx, (size_t)group_off[G] * sizeof(int32_t)));
     }
+    PSA_TRY(materialise_displacements(c, &slot, &disp, mean_pos_all));
 
     char*   rows = (char*)c->d_slab.ptr + row_bytes * (size_t)k_offset;
     float2* d_q = intensity ? nullptr : (float2*)rows;
@@ -755,11 +797,12 @@ int psa_debug_project_only(psa_ctx* c, int slot, const float* mean_pos_all, cons
     PSA_TRY(upload(c, c->d_mean_all, mean_pos_all, (size_t)N * 3 * sizeof(float)));
     if (idx) PSA_TRY(upload(c, c->d_idx, idx, (size_t)n_g * sizeof(int32_t)));
     ProjGeom g;
-    PSA_TRY(make_geom(c, slot, K, n_g, idx ? c->d_idx.as<int>() : nullptr, idx, (flags & PSA_F_DISPLACEMENTS) != 0, &g));
+    bool disp = (flags & PSA_F_DISPLACEMENTS) != 0;
+    PSA_TRY(materialise_displacements(c, &slot, &disp, mean_pos_all));
+    PSA_TRY(make_geom(c, slot, K, n_g, idx ? c->d_idx.as<int>() : nullptr, idx, disp, &g));
     const size_t bytes = (size_t)K * 3 * T * sizeof(float2);
     PSA_TRY(c->d_qwork.reserve(bytes));
-    PSA_TRY(project_group(c, slot, idx ? c->d_idx.as<int>() : nullptr, g,
-                          (flags & PSA_F_DISPLACEMENTS) != 0, c->d_qwork.as<float2>()));
+    PSA_TRY(project_group(c, slot, idx ? c->d_idx.as<int>() : nullptr, g, disp, c->d_qwork.as<float2>()));
     PSA_HIP_CHECK(hipMemcpyAsync(out_host, c->d_qwork.ptr, bytes, hipMemcpyDeviceToHost, c->stream));
     PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
     return PSA_OK;

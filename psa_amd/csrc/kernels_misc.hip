@@ -156,6 +156,28 @@ int launch_mean_over_frames(psa_ctx* c, const float* d_x, int64_t T, int64_t N, 
 }
 
 // ---------------------------------------------------------------------------
+// displacements                                   ref: sed_calculator.py:70-72
+// positions - mean_pos, one float32 subtraction per element, materialised like the reference's
+// temporary (so the fast projection kernels read it like velocities)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+subtract_mean_kernel(const float* __restrict__ x, const float* __restrict__ mean, float* __restrict__ out, int64_t T,
+                     int64_t cols) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    const float m = mean[j];
+    for (int64_t t = blockIdx.y; t < T; t += gridDim.y) out[t * cols + j] = __fsub_rn(x[t * cols + j], m);
+}
+
+int launch_subtract_mean(psa_ctx* c, const float* d_x, const float* d_mean, float* d_out, int64_t T, int64_t N) {
+    const int64_t cols = 3 * N;
+    dim3 grid((unsigned)((cols + 255) / 256), (unsigned)(T < 256 ? T : 256));
+    hipLaunchKernelGGL(subtract_mean_kernel, grid, dim3(256), 0, c->stream, d_x, d_mean, d_out, T, cols);
+    PSA_HIP_CHECK(hipGetLastError());
+    return PSA_OK;
+}
+
+// ---------------------------------------------------------------------------
 // largest |x| of a resident array, as float bits (non-negative floats order like unsigned
 // integers; a NaN or Inf anywhere makes the result >= 0x7f800000).  The split-precision
 // projection kernel derives from it the power of two that places the data at the top of the

@@ -83,6 +83,7 @@ struct DataSlot {
     DevBuf  buf;
     int64_t T = 0, N = 0;
     bool    valid = false;
+    uint64_t generation = 0;             // bumped whenever the contents change
     // largest |x| of the array (float bits), computed on first use after the contents change
     bool     absmax_known = false;
     unsigned absmax_bits = 0;
@@ -141,7 +142,11 @@ struct psa_ctx {
     int         k1_selector = PSA_K1_AUTO;
     int         compute_units = 0;
 
-    psa::DataSlot slot[PSA_NUM_SLOTS];
+    // [PSA_NUM_SLOTS] is internal: positions minus their mean (displacement mode), materialised on
+    // first use and kept while the positions and the mean stay the same
+    psa::DataSlot slot[PSA_NUM_SLOTS + 1];
+    std::vector<float> disp_mean;        // the mean the displacement array was built with
+    uint64_t           disp_source = 0;  // generation of the positions slot it was built from
 
     // per-call scratch
     psa::DevBuf d_kvec, d_mean_all, d_idx, d_mean_g, d_phase, d_qwork, d_fft_work, d_tables, d_absmax;
@@ -173,6 +178,7 @@ int launch_fill_synthetic(psa_ctx* c, float* d_v, int64_t T, int64_t N, uint64_t
                           const float* d_amp, const int* d_comp, const float* d_ct,
                           const float* d_st, const float* d_ca, const float* d_sa);
 int launch_mean_over_frames(psa_ctx* c, const float* d_x, int64_t T, int64_t N, float* d_mean);
+int launch_subtract_mean(psa_ctx* c, const float* d_x, const float* d_mean, float* d_out, int64_t T, int64_t N);
 int launch_absmax_bits(psa_ctx* c, const float* d_x, int64_t n, unsigned* d_out);
 int launch_absmax_blocks(psa_ctx* c, const float* d_x, int64_t T, int64_t N, unsigned* d_out);
 

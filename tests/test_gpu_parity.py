@@ -465,3 +465,27 @@ def test_results_come_in_recycled_page_locked_memory(engine, trajs):
     assert again.ctypes.data == address and rel_max(again, ref) <= TOL
     small = calc.calculate(mags[:4], vecs[:4]).sed                   # 12 KB: ordinary memory
     assert small.ctypes.data not in sum(_hip._pinned_pool._idle.values(), [])
+
+
+@pytest.mark.parametrize("idx", [None, [4, 9, 9, 60, 1, 17, 33, 2]])
+def test_displacement_mode_on_the_fast_kernels(engine, trajs, idx):
+    """use_displacements=True: positions - mean is materialised once on the device (the reference's
+    temporary, sed_calculator.py:70-72) and projected by the split-precision kernels; the array is
+    reused while positions and mean stay the same and rebuilt when they change."""
+    from psa_amd import _hip
+    d = trajs["a"]
+    calc = _calc(d, engine, use_displacements=True)
+    mags, vecs = calc.get_k_path([1, 1, 0], 2.0, 40)                 # f16 kernel
+    kw = {} if idx is None else {"basis_atom_indices": idx}
+    got = calc.calculate(mags, vecs, **kw)
+    ref, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], d["dt_ps"], vecs,
+                            use_displacements=True, **kw)
+    assert rel_max(got.sed, ref) <= TOL
+    again = calc.calculate(mags[:9], vecs[:9], **kw)                 # bf16 kernel, cached displacements
+    assert rel_max(again.sed, ref[:, :9]) <= TOL
+    try:                                                             # the float32 loader agrees
+        engine.set_k1(_hip.K1_MFMA32)
+        exact = calc.calculate(mags, vecs, **kw)
+    finally:
+        engine.set_k1(_hip.K1_AUTO)
+    assert rel_max(got.sed, exact.sed) <= 2e-6
