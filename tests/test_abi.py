@@ -67,3 +67,19 @@ def test_pack_groups():
     assert idx.tolist() == [3, 1, 2] and off.tolist() == [0, 2, 2, 3]
     with pytest.raises(ValueError, match="out of bounds"):
         _hip.pack_groups([np.array([-1])])
+
+
+def test_pinned_pool_degrades_to_ordinary_memory_without_a_gpu():
+    """No device: page-locking fails inside the library, the pool hands out a plain ndarray and keeps
+    no account of it."""
+    import numpy as np
+    from psa_amd import _hip
+    try:
+        if _hip.device_count() > 0:
+            pytest.skip("a GPU is present")
+    except _hip.PsaHipError:
+        pass                                                            # no ROCm device at all
+    a = _hip.pinned_empty((1 << 19,), np.float32)
+    a[:] = 2.0
+    assert a.flags.writeable and float(a.sum()) == float(1 << 20) and _hip._pinned_pool._live_bytes == 0
+    assert _hip.pinned_empty((8,), np.complex64).shape == (8,)          # small: never page-locked
