@@ -108,7 +108,7 @@ int psa_mean_positions(psa_ctx* ctx, int slot, float* mean_host /* (N,3) */);
 /* ---- the hot path -------------------------------------------------------
  * psa_sed_project: for each of the G atom groups, for the K_local k-vectors given,
  *     P[k,a]   = exp(i * (k . mean_pos[idx[a]]))            float32 FMA chain + sincos
- *     q[k,c,t] = sum_a  d[t, idx[a], c] * P[k,a]            fp32 MFMA, LDS-staged tiles
+ *     q[k,c,t] = sum_a  d[t, idx[a], c] * P[k,a]            split-precision f16 MFMA (fp32-equivalent), LDS-staged tiles
  *     S[k,c,w] = FFT_t(q) / T                               batched rocFFT, in place
  * and either keeps S of the (single) group as complex64, or accumulates
  * sum_c |S|^2 over groups as float32 (PSA_F_INTENSITY).  The result stays on the

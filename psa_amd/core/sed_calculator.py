@@ -6,7 +6,7 @@ src/psa/core/sed_calculator.py): same constructor, same `get_k_path` / `get_k_gr
 `calculate` / `calculate_chiral_phase` signatures, attributes (`a1..a3`, `b1..b3`,
 `recip_vecs_prim`, `dt_ps`, `traj`, `use_displacements`) and ValueErrors.  What differs is
 where the arithmetic runs: the reference's `_calculate_sed_for_group` (:58-84, NumPy
-einsum + pocketfft) is replaced by libpsa_hip.so (phase table -> fp32-MFMA projection ->
+einsum + pocketfft) is replaced by libpsa_hip.so (phase table -> split-precision f16-MFMA projection, fp32-equivalent ->
 batched rocFFT -> epilogue) through `psa_amd._hip.Engine`.  There is no CPU path here.
 
 `calculate_kpath_sed` / `calculate_kgrid_sed` / `calculate_chiral_sed` are the composites

@@ -108,6 +108,58 @@ CALC_CASES = [
          kw=dict(basis_atom_types=[1, 2], summation_mode="incoherent")),
 ]
 
+# `calculate` cases with more than 16 k-vectors: these are the ones the product-default "2 x f16"
+# projection kernel serves (api.hip make_geom: K > 16), in all its forms -- 64-row blocks (K <= 32)
+# and 128-row blocks, row DMA (all atoms in order) and gather DMA (index lists / type groups),
+# the materialised-displacement array, phases up to ~200 rad.  The reference output is stored as
+# the full intensity plus every WIDE_SED_STRIDE-th frequency row of `sed` (keeps the fixture small).
+WIDE_SED_STRIDE = 4
+_K24 = ("path", "100", 1.0, 24, None)
+_K40 = ("path", [1, 1, 0], 2.0, 40, None)
+_K140 = ("path", "100", 3.0, 140, None)
+CALC_WIDE_CASES = [
+    dict(name="w_coh_all_k24", traj="a", k=_K24),
+    dict(name="w_coh_all_k40", traj="a", k=_K40),
+    dict(name="w_coh_all_k140", traj="a", k=_K140),
+    dict(name="w_idx_dup_k40", traj="a", k=_K40,
+         kw=dict(basis_atom_indices=nd([7, 3, 3, 60, 12, 12, 41, 0, 63, 5, 18]))),
+    dict(name="w_idx_list_k140", traj="a", k=_K140,
+         kw=dict(basis_atom_indices=list(range(1, 64, 2)) + [2, 2, 50])),
+    dict(name="w_inc_types12_k24", traj="a", k=_K24,
+         kw=dict(basis_atom_types=[1, 2], summation_mode="incoherent")),
+    dict(name="w_inc_types_nested_k140", traj="a", k=_K140,
+         kw=dict(basis_atom_types=[[1], [2, 3]], summation_mode="incoherent")),
+    dict(name="w_coh_types12_k40", traj="a", k=_K40, kw=dict(basis_atom_types=[1, 2])),
+    dict(name="w_displacements_k40", traj="a", k=_K40, ctor=dict(use_displacements=True)),
+    dict(name="w_displacements_inc_k24", traj="a", k=_K24, ctor=dict(use_displacements=True),
+         kw=dict(basis_atom_types=[1, 2], summation_mode="incoherent")),
+    dict(name="w_large_phase_k40", traj="b", k=("path", [1, 1, 0], 4.0, 40, None)),
+    dict(name="w_large_phase_k140", traj="b", k=("path", "x", 4.0, 140, 2.491)),
+    dict(name="w_large_phase_inc_k40", traj="b", k=("path", [1, 1, 0], 4.0, 40, None),
+         kw=dict(basis_atom_types=[1, 2], summation_mode="incoherent")),
+    dict(name="w_nonpow2_T100_k24", traj="c", k=("path", "z", 2.0, 24, None)),
+    dict(name="w_grid_xy_6x7", traj="a", k=("grid", "xy", (-1.5, 1.5), (-1.0, 1.0), 6, 7, 0.25)),
+]
+
+
+def c1_inputs():
+    """BASELINE configuration 1 (512 atoms x 4096 steps x 32 k-points, [100], bz 4.0, dt 0.02:
+    examples/Si_config.yaml's shape) as arrays: the synthetic velocities of psa_amd/synth.py
+    (bit-identical NumPy twin of the device generator) and jittered positions from a seeded
+    NumPy generator.  Built the same way by make_golden.py (which feeds them to the real
+    reference) and by the GPU test."""
+    from psa_amd import synth
+    spec, req = synth.baseline_spec("C1")
+    r0, types, box = synth.lattice(spec.cells)
+    tables = synth.mode_tables(spec, r0)
+    vel = np.concatenate([synth.velocities_block(spec, tables, t, 256) for t in range(0, spec.n_frames, 256)])
+    rng = np.random.default_rng(101)
+    pos = (r0[None] + 0.05 * rng.standard_normal(vel.shape, dtype=np.float32)).astype(np.float32)
+    return spec, req, dict(positions=pos, velocities=vel, types=types, box_matrix=box,
+                           timesteps=np.arange(spec.n_frames, dtype=np.float32),
+                           box_lengths=np.diag(box).copy(), box_tilts=np.zeros(3, np.float32))
+
+
 KPATH_CASES = [
     dict(traj="a", spec="100", cov=1.0, n_k=32, lat=None),
     dict(traj="a", spec=[1, 1, 0], cov=4.0, n_k=250, lat=None),

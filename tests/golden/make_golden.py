@@ -93,6 +93,50 @@ def main():
     out["seam_empty/sed"] = calc._calculate_sed_for_group(vecs, np.array([], int), mean)
     np.savez_compressed(HERE / "calc_cases.npz", **out)
 
+    # ---- calculate() with more than 16 k-vectors (the "2 x f16" kernel's territory) ----------
+    out = {}
+    for case in C.CALC_WIDE_CASES:
+        calc = make_calc(case["traj"], **case.get("ctor", {}))
+        mags, vecs, shape = C.k_from_spec(calc, case["k"])
+        kw = C.realise_kw(case.get("kw", {}))
+        if shape is not None:
+            kw["k_grid_shape"] = shape
+        sed = calc.calculate(mags, vecs, **kw)
+        n = case["name"]
+        out[f"{n}/k_mags"], out[f"{n}/k_vecs"] = mags, vecs
+        out[f"{n}/sed_rows"] = sed.sed[::C.WIDE_SED_STRIDE]
+        out[f"{n}/sed_shape"] = np.array(sed.sed.shape)
+        out[f"{n}/is_complex"] = np.array(sed.is_complex)
+        out[f"{n}/intensity"] = sed.intensity if sed.is_complex else sed.sed
+    np.savez_compressed(HERE / "calc_wide.npz", **out)
+
+    # ---- BASELINE configuration 1 through the real reference (full size) -----------------------
+    sys.path.insert(0, str(HERE.parent.parent))
+    spec, req, d = C.c1_inputs()
+    tr = Trajectory(d["positions"], d["velocities"], d["types"], d["timesteps"],
+                    d["box_matrix"], d["box_lengths"], d["box_tilts"], spec.dt_ps)
+    calc = SEDCalculator(tr, *spec.cells)
+    mags, vecs = calc.get_k_path(req["direction"], req["bz_coverage"], req["n_k"])
+    sed = calc.calculate(mags, vecs)
+    inc = calc.calculate(mags, vecs, basis_atom_types=[1, 2], summation_mode="incoherent")
+    rows = np.array([0, 1, 255, 256, 819, 2048, 4095])
+    np.savez_compressed(HERE / "c1_reference.npz", k_mags=mags, k_vecs=vecs, intensity=sed.intensity,
+                        sed_rows=sed.sed[rows], rows=rows, freqs=sed.freqs,
+                        intensity_incoherent_types12=inc.sed)
+
+    # ---- SED.save written by the reference (six .npy files incl. grid shape and phase) ---------
+    import shutil
+    saved = HERE / "sed_saved"
+    shutil.rmtree(saved, ignore_errors=True)
+    saved.mkdir()
+    calc = make_calc("a")
+    mags, vecs, shape = calc.get_k_grid("xy", (-1.5, 1.5), (-1.0, 1.0), 3, 4, 0.25)
+    sed = calc.calculate(mags, vecs, k_grid_shape=shape)
+    sed.phase = calc.calculate_chiral_phase(sed.sed[:, :, 0], sed.sed[:, :, 1], "C")
+    sed.save(saved / "grid_xy_phase")
+    mags, vecs = calc.get_k_path("100", 1.0, 8)
+    calc.calculate(mags, vecs, basis_atom_types=[1, 2], summation_mode="incoherent").save(saved / "path_inc")
+
     # ---- k generators, ctor attributes -----------------------------------
     out = {}
     for i, kc in enumerate(C.KPATH_CASES):
@@ -130,7 +174,6 @@ def main():
     np.savez_compressed(HERE / "chiral_cases.npz", **out)
 
     # ---- trajectory .npy cache written by the reference's own loader ------------------------
-    import shutil
     from psa.io.loader import TrajectoryLoader
     cache = HERE / "npy_cache"
     shutil.rmtree(cache, ignore_errors=True)

@@ -112,6 +112,84 @@ def test_calculate_matches_reference_golden(case, golden, trajs, engine):
     assert (sed.k_grid_shape or ()) == tuple(golden[f"{name}/grid_shape"])
 
 
+@pytest.mark.parametrize("case", C.CALC_WIDE_CASES, ids=[c["name"] for c in C.CALC_WIDE_CASES])
+def test_calculate_wide_matches_reference_golden(case, golden, trajs, engine):
+    """More than 16 k-vectors: the product-default "2 x f16" projection kernel (64- and 128-row
+    blocks, whole trajectory and index lists / type groups, displacement mode, phases up to
+    ~200 rad) held directly to REFERENCE output (tests/golden/calc_wide.npz: whole intensity,
+    every WIDE_SED_STRIDE-th complex row)."""
+    d = trajs[case["traj"]]
+    name = case["name"]
+    calc = _calc(d, engine, **case.get("ctor", {}))
+    mags, vecs, shape = C.k_from_spec(calc, case["k"])
+    np.testing.assert_allclose(vecs, golden[f"{name}/k_vecs"], rtol=3e-7, atol=1e-9)
+    mags, vecs = golden[f"{name}/k_mags"], golden[f"{name}/k_vecs"]
+    kw = C.realise_kw(case.get("kw", {}))
+    if shape is not None:
+        kw["k_grid_shape"] = shape
+    sed = calc.calculate(mags, vecs, **kw)
+    assert sed.sed.shape == tuple(golden[f"{name}/sed_shape"])
+    assert sed.is_complex == bool(golden[f"{name}/is_complex"])
+    assert rel_max(sed.intensity if sed.is_complex else sed.sed, golden[f"{name}/intensity"]) <= TOL
+    assert rel_max(sed.sed[::C.WIDE_SED_STRIDE], golden[f"{name}/sed_rows"]) <= TOL
+    # a second call takes the cached split planes of the group (built on first use)
+    again = calc.calculate(mags, vecs, **kw)
+    assert rel_max(again.intensity if again.is_complex else again.sed, golden[f"{name}/intensity"]) <= TOL
+
+
+def test_config1_matches_reference(engine):
+    """BASELINE configuration 1 at full size -- 512 atoms x 4096 steps x 32 k-points, [100] path,
+    bz 4.0 -- through the public API against the REAL reference's output (c1_reference.npz)."""
+    from conftest import GOLDEN
+    from psa_amd import SEDCalculator, Trajectory
+    spec, req, d = C.c1_inputs()
+    with np.load(GOLDEN / "c1_reference.npz") as z:
+        ref = {k: z[k] for k in z.files}
+    tr = Trajectory(d["positions"], d["velocities"], d["types"], d["timesteps"], d["box_matrix"],
+                    d["box_lengths"], d["box_tilts"], spec.dt_ps)
+    calc = SEDCalculator(tr, *spec.cells).attach(engine=engine)
+    mags, vecs = calc.get_k_path(req["direction"], req["bz_coverage"], req["n_k"])
+    np.testing.assert_allclose(vecs, ref["k_vecs"], rtol=3e-7, atol=1e-9)
+    sed = calc.calculate(ref["k_mags"], ref["k_vecs"])
+    assert sed.sed.shape == (4096, 32, 3)
+    np.testing.assert_array_equal(sed.freqs, ref["freqs"])
+    assert rel_max(sed.intensity, ref["intensity"]) <= TOL
+    assert rel_max(sed.sed[ref["rows"]], ref["sed_rows"]) <= TOL
+    inc = calc.calculate(ref["k_mags"], ref["k_vecs"], basis_atom_types=[1, 2], summation_mode="incoherent")
+    assert not inc.is_complex and rel_max(inc.sed, ref["intensity_incoherent_types12"]) <= TOL
+    # the composite the north star names
+    via = calc.calculate_kpath_sed(req["direction"], req["bz_coverage"], req["n_k"])
+    assert rel_max(via.intensity, ref["intensity"]) <= TOL
+
+
+def test_integration_md_seam_patch_runs_verbatim(golden, trajs):
+    """INTEGRATION.md, option B: the ctypes stub a PSA maintainer would add (`HipSeam`, bound to
+    psa_sed_calculate) is executed exactly as printed there -- only the library path is made
+    absolute -- and must reproduce the reference's `_calculate_sed_for_group` output."""
+    import re
+    import types as pytypes
+    from conftest import ROOT
+    from psa_amd import _hip
+    text = (ROOT / "INTEGRATION.md").read_text()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = next(b for b in blocks if "class HipSeam" in b)
+    assert 'C.CDLL("libpsa_hip.so")' in stub
+    stub = stub.replace('C.CDLL("libpsa_hip.so")', f'C.CDLL("{_hip.LIB_PATH}")')
+    mod = pytypes.ModuleType("_psa_hip_from_integration_md")
+    exec(compile(stub, "INTEGRATION.md", "exec"), mod.__dict__)
+    d = trajs["a"]
+    traj = pytypes.SimpleNamespace(positions=d["positions"], velocities=d["velocities"])
+    seam = mod.HipSeam(traj, use_displacements=False)
+    got = seam(golden["seam/k_vecs"], golden["seam/idx"], golden["seam/mean_pos"])
+    assert got.dtype == np.complex64 and rel_max(got, golden["seam/sed"]) <= TOL
+    # a k-list long enough for the default kernel, all atoms, both data modes
+    for disp in (False, True):
+        seam = mod.HipSeam(traj, use_displacements=disp)
+        case = "w_displacements_k40" if disp else "w_coh_all_k40"
+        got = seam(golden[f"{case}/k_vecs"], np.arange(d["positions"].shape[1]), O.mean_positions(d["positions"]))
+        assert rel_max(got[::C.WIDE_SED_STRIDE], golden[f"{case}/sed_rows"]) <= TOL
+
+
 def test_seam_matches_reference(golden, trajs, engine):
     calc = _calc(trajs["a"], engine)
     got = calc._calculate_sed_for_group(golden["seam/k_vecs"], golden["seam/idx"], golden["seam/mean_pos"])

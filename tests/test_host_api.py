@@ -130,6 +130,29 @@ def test_sed_save_load_round_trip(tmp_path):
 
 
 # ---------------------------------------------------------------- constructor, k generators
+def test_sed_files_written_by_the_reference_load(tmp_path):
+    """tests/golden/sed_saved/ holds `SED.save` output of the REFERENCE (make_golden.py): a k-grid
+    result with phase and grid shape, and an incoherent k-path result.  `psa_amd.SED.load` reads
+    them, and what `psa_amd.SED.save` writes back is byte-for-byte the reference's files."""
+    from conftest import GOLDEN
+    from psa_amd import SED
+    src = GOLDEN / "sed_saved"
+    grid = SED.load(src / "grid_xy_phase")
+    assert grid.sed.shape == (128, 12, 3) and grid.sed.dtype == np.complex64
+    assert grid.k_grid_shape == (3, 4) and grid.phase.shape == (128, 12) and grid.phase.dtype == np.float32
+    assert grid.k_points.size == 0 and grid.k_vectors.shape == (12, 3) and grid.freqs.dtype == np.float64
+    path = SED.load(src / "path_inc")
+    assert path.sed.shape == (128, 8) and path.sed.dtype == np.float32
+    assert path.k_grid_shape is None and path.phase is None
+    for name, obj in (("grid_xy_phase", grid), ("path_inc", path)):
+        obj.save(tmp_path / name)
+        ours = sorted(f.name for f in tmp_path.glob(f"{name}.*"))
+        theirs = sorted(f.name for f in src.glob(f"{name}.*"))
+        assert ours == theirs
+        for f in theirs:
+            assert (tmp_path / f).read_bytes() == (src / f).read_bytes(), f
+
+
 def test_constructor_attributes(golden, trajs):
     for t, d in trajs.items():
         calc = make_calculator(d)

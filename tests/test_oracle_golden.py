@@ -42,6 +42,43 @@ def test_calculate_matches_reference(case, golden, trajs):
     assert rel_max(O.intensity(sed), golden[f"{name}/intensity"]) <= 2e-6
 
 
+@pytest.mark.parametrize("case", C.CALC_WIDE_CASES, ids=[c["name"] for c in C.CALC_WIDE_CASES])
+def test_calculate_wide_matches_reference(case, golden, trajs):
+    """More than 16 k-vectors (the default GPU kernel's territory): the oracle against the
+    reference's intensity (whole) and complex rows (every WIDE_SED_STRIDE-th)."""
+    d = trajs[case["traj"]]
+    name = case["name"]
+    mags, vecs = _k_for(case, d)
+    np.testing.assert_allclose(vecs, golden[f"{name}/k_vecs"], rtol=3e-7, atol=1e-9)
+    vecs = golden[f"{name}/k_vecs"]
+    kw = C.realise_kw(case.get("kw", {}))
+    sed, _, is_complex = O.calculate(
+        d["positions"], d["velocities"], d["types"], d["dt_ps"], vecs,
+        use_displacements=case.get("ctor", {}).get("use_displacements", False), **kw)
+    assert tuple(golden[f"{name}/sed_shape"]) == sed.shape
+    assert bool(golden[f"{name}/is_complex"]) == is_complex
+    assert rel_max(sed[::C.WIDE_SED_STRIDE], golden[f"{name}/sed_rows"]) <= 2e-6
+    assert rel_max(O.intensity(sed) if is_complex else sed, golden[f"{name}/intensity"]) <= 2e-6
+
+
+def test_config1_matches_reference():
+    """BASELINE configuration 1 at full size (512 x 4096 x 32): the oracle against the real
+    reference's output captured by make_golden.py."""
+    from conftest import GOLDEN
+    spec, req, d = C.c1_inputs()
+    with np.load(GOLDEN / "c1_reference.npz") as z:
+        ref = {k: z[k] for k in z.files}
+    mags, vecs = O.k_path(d["box_matrix"], *spec.cells, req["direction"], req["bz_coverage"], req["n_k"])
+    np.testing.assert_allclose(vecs, ref["k_vecs"], rtol=3e-7, atol=1e-9)
+    sed, freqs, _ = O.calculate(d["positions"], d["velocities"], d["types"], spec.dt_ps, ref["k_vecs"])
+    np.testing.assert_array_equal(freqs, ref["freqs"])
+    assert rel_max(O.intensity(sed), ref["intensity"]) <= 2e-6
+    assert rel_max(sed[ref["rows"]], ref["sed_rows"]) <= 2e-6
+    inc, _, cx = O.calculate(d["positions"], d["velocities"], d["types"], spec.dt_ps, ref["k_vecs"],
+                             basis_atom_types=[1, 2], summation_mode="incoherent")
+    assert not cx and rel_max(inc, ref["intensity_incoherent_types12"]) <= 2e-6
+
+
 def test_seam_matches_reference(golden, trajs):
     d = trajs["a"]
     got = O.sed_for_group(d["positions"], d["velocities"], golden["seam/k_vecs"],
