@@ -180,7 +180,7 @@ def main():
         if group.has_result:
             engine.finalize(T, K, intensity_out, fetch=False)
             if not intensity_out:
-                engine._lib.psa_result_intensity(engine._h, None)
+                engine._lib.psa_result_intensity(engine._h, None, 0)
 
     for _ in range(args.warmup):
         step()

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PSA_HIP_ABI_VERSION 1
+#define PSA_HIP_ABI_VERSION 2
 
 /* error codes */
 #define PSA_OK          0
@@ -57,9 +57,11 @@ extern "C" {
                                   /* default: complex64 (T,K,3) of the (single) group (:296-311) */
 
 /* projection-kernel selector (diagnostics; PSA_K1_AUTO is the product path) */
-#define PSA_K1_AUTO   0  /* split-precision (fp32-equivalent) MFMA kernels for velocity data: "2 x f16"
-                            for groups with more than 16 k-vectors, "3 x bf16" below that and for
-                            arrays holding NaN/Inf; exact-fp32 MFMA kernel for displacement mode */
+#define PSA_K1_AUTO   0  /* split-precision (fp32-equivalent) MFMA kernels: "2 x f16" for groups with more
+                            than 16 k-vectors -- from the group's cached split planes when it has them
+                            (PSA_OPT_PLANES), splitting on the fly otherwise -- "3 x bf16" below that and
+                            for arrays holding NaN/Inf; displacement mode projects a materialised
+                            positions - mean array the same way */
 #define PSA_K1_WAVE   1  /* LDS-staged VALU kernel with wavefront shuffle sums       */
 #define PSA_K1_MFMA32 2  /* always the exact-fp32 MFMA tile kernel                   */
 #define PSA_K1_SPLIT_BF16 3  /* "3 x bf16" split-precision kernel for every velocity-mode group */
@@ -79,6 +81,22 @@ int         psa_create(int device, psa_ctx** out);
 int         psa_destroy(psa_ctx* ctx);
 int         psa_synchronize(psa_ctx* ctx);
 int         psa_set_k1(psa_ctx* ctx, int selector);     /* PSA_K1_* */
+/* Tunables of the product path (defaults in brackets):
+ *   PSA_OPT_PLANES        [1] keep, per atom group, the group's data scaled, split into its two
+ *                             float16 pieces and laid out in MFMA-fragment order ("split planes",
+ *                             4 bytes per value like the float32 array, the group's atoms compacted)
+ *                             and project from them; 0 = always split on the fly
+ *   PSA_OPT_PLANES_BUDGET [0] bytes of HBM the plane cache may hold; 0 = 45 % of the device.  Sets
+ *                             are evicted least-recently-used; a group that does not fit is
+ *                             projected by the on-the-fly kernels.  The float32 slot is never dropped.
+ *   PSA_OPT_PLANES_EAGER  [0] 1 = build an index-list group's planes on its first projection
+ *                             (default: on the second with the same list; "all atoms" always first)
+ *   PSA_OPT_PLANES_MIN_K  [17] shortest k-list that is projected from planes */
+#define PSA_OPT_PLANES         0
+#define PSA_OPT_PLANES_BUDGET  1
+#define PSA_OPT_PLANES_EAGER   2
+#define PSA_OPT_PLANES_MIN_K   3
+int         psa_set_option(psa_ctx* ctx, int option, int64_t value);
 /* device name / CU count / HBM bytes of the context's GPU */
 int         psa_device_info(psa_ctx* ctx, char* name, int name_len,
                             int* compute_units, int64_t* hbm_bytes);
@@ -86,6 +104,9 @@ int         psa_device_info(psa_ctx* ctx, char* name, int name_len,
 /* ---- trajectory residency ---------------------------------------------
  * Trajectory.velocities / .positions are (T, N, 3) float32 C-order
  * (src/psa/core/trajectory.py:20-23); they stay in HBM in exactly that layout. */
+/* psa_data_upload streams the array through two page-locked staging buffers (filled by a few
+ * host threads, drained by hipMemcpyAsync on a copy stream) -- the source may be pageable or a
+ * memory-mapped .npy cache (src/psa/io/loader.py:48-79). */
 int psa_data_upload(psa_ctx* ctx, int slot, const float* host, int64_t T, int64_t N);
 int psa_data_alloc(psa_ctx* ctx, int slot, int64_t T, int64_t N);
 int psa_data_download(psa_ctx* ctx, int slot, float* host, int64_t t0, int64_t nt);
@@ -95,8 +116,10 @@ int psa_data_shape(psa_ctx* ctx, int slot, int64_t* T, int64_t* N);
 /* Fill a slot, already allocated with psa_data_alloc, with the synthetic
  * trajectory of psa_amd/synth.py (bit-identical NumPy twin there):
  *   v[t,a,c] = noise(seed,t,a,c) + sum_m [c==mode_comp[m]] amp[m]*(ct[m,t]*ca[m,a] + st[m,t]*sa[m,a])
- * tables are (n_modes, T) / (n_modes, N) float32, host. */
-int psa_data_fill_synthetic(psa_ctx* ctx, int slot, uint64_t seed, int n_modes,
+ * tables are (n_modes, T) / (n_modes, N) float32, host.  The slot holds frames
+ * [t_offset, t_offset + T) of the synthetic trajectory (noise counter and ct/st rows of those
+ * frames): a frame-sharded rank generates its own slice. */
+int psa_data_fill_synthetic(psa_ctx* ctx, int slot, uint64_t seed, int64_t t_offset, int n_modes,
                             const float* amp, const int32_t* mode_comp,
                             const float* ct, const float* st,
                             const float* ca, const float* sa);
@@ -133,16 +156,38 @@ int psa_sed_project(psa_ctx* ctx, int slot,
                     const int32_t* group_idx, const int64_t* group_off, int32_t G,
                     int32_t flags);
 
+/* The same for an array that is not resident yet: uploads `host` (T,N,3) into the slot AND
+ * projects, overlapped -- the array travels in chunks of frames through the staging pipeline of
+ * psa_data_upload, and each chunk's frames are projected (first atom group; the projection is
+ * independent per frame, sed_calculator.py:80-81) on the compute stream while the next chunk is
+ * on the PCIe link; the rocFFT plan is built meanwhile on a host thread.  Further groups, the FFT
+ * and the epilogue follow on the resident array.  Result and state as after psa_data_upload +
+ * psa_sed_project (all K on this device). */
+int psa_sed_project_upload(psa_ctx* ctx, int slot, const float* host, int64_t T, int64_t N,
+                           const float* mean_pos_all, const float* k_vectors, int64_t K,
+                           const int32_t* group_idx, const int64_t* group_off, int32_t G,
+                           int32_t flags);
+
 /* Transpose the K_total-row slab to the reference's layout -- (T,K,3) complex64
  * (sed_calculator.py:277) or (T,K) float32 (:280) -- and copy it to out_host
- * (may be NULL: the result then only exists on the device, see psa_result_*). */
-int psa_sed_finalize(psa_ctx* ctx, void* out_host);
+ * (may be NULL: the result then only exists on the device, see psa_result_*).
+ * out_bytes is the size of the caller's buffer and must be exactly the result's
+ * (24*T*K or 4*T*K): a mismatch is PSA_EINVAL, nothing is copied. */
+int psa_sed_finalize(psa_ctx* ctx, void* out_host, size_t out_bytes);
 
 /* one-call convenience: project all K on this device, finalize, copy out */
 int psa_sed_calculate(psa_ctx* ctx, int slot, const float* mean_pos_all,
                       const float* k_vectors, int64_t K,
                       const int32_t* group_idx, const int64_t* group_off, int32_t G,
-                      int32_t flags, void* out_host);
+                      int32_t flags, void* out_host, size_t out_bytes);
+
+/* One (k, omega) bin: S[c] = FFT_t(q)[i_w] / T for ONE k-vector and one atom group, as 3
+ * complex64 -- what iSED consumes of a group's spectrum (sed_calculator.py:483, :494-499: only
+ * sed[i_w, i_k, :] of the full path spectrum is used).  One pass over the trajectory and one DFT
+ * dot instead of K projections and 3K FFTs.  idx NULL = all atoms. */
+int psa_sed_single_bin(psa_ctx* ctx, int slot, const float* mean_pos_all, const float* k_vector,
+                       const int32_t* idx, int64_t n_g, int32_t flags, int64_t i_w,
+                       float* out_c64x3 /* 6 floats */);
 
 /* Raw access to rows [row0, row0+nrows) of the k-major slab (complex64 (nrows,3,T) or float32
  * (nrows,T), whichever the last psa_sed_project produced): lets a host transport stand in for
@@ -152,10 +197,10 @@ int psa_slab_write(psa_ctx* ctx, int64_t row0, int64_t nrows, const void* host);
 
 /* SED.intensity of the finalized complex result, on the device:
  * (T,K) float32 = sum_c |S|^2   (src/psa/core/sed.py:22-24) */
-int psa_result_intensity(psa_ctx* ctx, float* out_host /* (T,K) */);
+int psa_result_intensity(psa_ctx* ctx, float* out_host /* (T,K) */, size_t out_bytes);
 /* chiral phase, option "C", of components (c1, c2) of the finalized complex
  * result: (T,K) float32           (sed_calculator.py:344-350) */
-int psa_result_chiral_phase(psa_ctx* ctx, int c1, int c2, float* out_host);
+int psa_result_chiral_phase(psa_ctx* ctx, int c1, int c2, float* out_host, size_t out_bytes);
 
 /* stage timings of the last project/finalize on this context, milliseconds:
  * [0] host->device uploads  [1] phase table  [2] projection  [3] FFT
@@ -175,6 +220,14 @@ int psa_debug_project_only(psa_ctx* ctx, int slot, const float* mean_pos_all,
                            const float* k_vectors, int64_t K,
                            const int32_t* idx, int64_t n_g, int32_t flags,
                            void* out_host);
+/* the same for frames [t_begin, t_begin + t_count) only, written into those columns of a zeroed
+ * (K,3,T) slab (what a frame-sharded or streaming projection does per piece) */
+int psa_debug_project_frames(psa_ctx* ctx, int slot, const float* mean_pos_all,
+                             const float* k_vectors, int64_t K,
+                             const int32_t* idx, int64_t n_g, int32_t flags,
+                             int64_t t_begin, int64_t t_count, void* out_host);
+/* number of plane sets in the cache and their bytes */
+int psa_debug_plane_cache(psa_ctx* ctx, int64_t* n_sets, int64_t* bytes);
 
 /* ---- k-point sharding over the GPUs of a node (one process per GPU) ------
  * rank 0 calls psa_comm_unique_id and ships the 128 bytes to the other ranks by
@@ -188,6 +241,31 @@ int psa_comm_init(psa_ctx* ctx, const void* unique_id, int rank, int nranks);
 int psa_comm_destroy(psa_ctx* ctx);
 int psa_sed_gather(psa_ctx* ctx, int root, const int64_t* k_offsets, const int64_t* k_counts);
 int psa_comm_barrier(psa_ctx* ctx);
+
+/* ---- frame sharding: one exchange step before the FFT -------------------------------
+ * The projection is linear in atoms and independent per frame (sed_calculator.py:80-81), the FFT
+ * runs along frames (:83).  Rank r holds only frames [t_offsets[r], +t_counts[r]) of the
+ * trajectory in its slot (1/n of the array), projects ALL K k-vectors on them, then an
+ * all-to-all over RCCL hands every rank the frames it lacks of ITS block of k rows
+ * [k_offsets[r], +k_counts[r]); FFT and epilogue run on those rows, which end up in the same
+ * k-major slab rows as with k-sharding -- psa_sed_gather / psa_sed_finalize follow unchanged.
+ * Per atom group (G groups need PSA_F_INTENSITY as usual):
+ *     psa_sed_fs_project   q_local (K_total,3,T_local) of the group, on the device
+ *     psa_sed_fs_exchange  the all-to-all (grouped ncclSend/ncclRecv, direct links)
+ *                          -- or psa_sed_fs_read / psa_sed_fs_write when a host transport stands in
+ *     psa_sed_fs_finish    FFT over T_total of my rows, then complex rows into the slab or
+ *                          |.|^2 accumulated into it (first_group: overwrite) */
+int psa_sed_fs_project(psa_ctx* ctx, int slot, const float* mean_pos_all,
+                       const float* k_vectors, int64_t K_total,
+                       const int32_t* idx, int64_t n_g, int32_t flags,
+                       int64_t T_total, int64_t k_offset, int64_t k_count);
+int psa_sed_fs_exchange(psa_ctx* ctx, const int64_t* t_offsets, const int64_t* t_counts,
+                        const int64_t* k_offsets, const int64_t* k_counts);
+/* rows [k0, k0+nk) of q_local as (nk,3,T_local) complex64 */
+int psa_sed_fs_read(psa_ctx* ctx, int64_t k0, int64_t nk, void* host);
+/* frames [t0, t0+nt) of my rows, (k_count,3,nt) complex64 */
+int psa_sed_fs_write(psa_ctx* ctx, int64_t t0, int64_t nt, const void* host);
+int psa_sed_fs_finish(psa_ctx* ctx, int32_t first_group);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,8 @@ LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libpsa_hip.so"
 SLOT_VELOCITIES, SLOT_POSITIONS = 0, 1
 F_DISPLACEMENTS, F_INTENSITY = 0x1, 0x2
 K1_AUTO, K1_WAVE, K1_MFMA32, K1_SPLIT_BF16 = 0, 1, 2, 3
+OPT_PLANES, OPT_PLANES_BUDGET, OPT_PLANES_EAGER, OPT_PLANES_MIN_K = 0, 1, 2, 3
+ABI_VERSION = 2
 UNIQUE_ID_BYTES = 128
 TIMING_NAMES = ("h2d", "phase", "project", "fft", "epilogue", "gather", "transpose", "d2h")
 
@@ -40,35 +42,48 @@ SIGNATURES = {
     "psa_destroy": (C.c_int, [_ctx]),
     "psa_synchronize": (C.c_int, [_ctx]),
     "psa_set_k1": (C.c_int, [_ctx, C.c_int]),
+    "psa_set_option": (C.c_int, [_ctx, C.c_int, C.c_int64]),
     "psa_device_info": (C.c_int, [_ctx, C.c_char_p, C.c_int, C.POINTER(C.c_int), _i64p]),
     "psa_data_upload": (C.c_int, [_ctx, C.c_int, _f32p, C.c_int64, C.c_int64]),
     "psa_data_alloc": (C.c_int, [_ctx, C.c_int, C.c_int64, C.c_int64]),
     "psa_data_download": (C.c_int, [_ctx, C.c_int, _f32p, C.c_int64, C.c_int64]),
     "psa_data_release": (C.c_int, [_ctx, C.c_int]),
     "psa_data_shape": (C.c_int, [_ctx, C.c_int, _i64p, _i64p]),
-    "psa_data_fill_synthetic": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_int, _f32p, _i32p,
+    "psa_data_fill_synthetic": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_int64, C.c_int, _f32p, _i32p,
                                           _f32p, _f32p, _f32p, _f32p]),
     "psa_mean_positions": (C.c_int, [_ctx, C.c_int, _f32p]),
     "psa_sed_project": (C.c_int, [_ctx, C.c_int, _f32p, _f32p, C.c_int64, C.c_int64, C.c_int64,
                                   _i32p, _i64p, C.c_int32, C.c_int32]),
-    "psa_sed_finalize": (C.c_int, [_ctx, C.c_void_p]),
+    "psa_sed_project_upload": (C.c_int, [_ctx, C.c_int, _f32p, C.c_int64, C.c_int64, _f32p, _f32p, C.c_int64,
+                                         _i32p, _i64p, C.c_int32, C.c_int32]),
+    "psa_sed_finalize": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
     "psa_sed_calculate": (C.c_int, [_ctx, C.c_int, _f32p, _f32p, C.c_int64, _i32p, _i64p,
-                                    C.c_int32, C.c_int32, C.c_void_p]),
+                                    C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
+    "psa_sed_single_bin": (C.c_int, [_ctx, C.c_int, _f32p, _f32p, _i32p, C.c_int64, C.c_int32, C.c_int64, _f32p]),
     "psa_slab_read": (C.c_int, [_ctx, C.c_int64, C.c_int64, C.c_void_p]),
     "psa_slab_write": (C.c_int, [_ctx, C.c_int64, C.c_int64, C.c_void_p]),
-    "psa_result_intensity": (C.c_int, [_ctx, _f32p]),
-    "psa_result_chiral_phase": (C.c_int, [_ctx, C.c_int, C.c_int, _f32p]),
+    "psa_result_intensity": (C.c_int, [_ctx, _f32p, C.c_size_t]),
+    "psa_result_chiral_phase": (C.c_int, [_ctx, C.c_int, C.c_int, _f32p, C.c_size_t]),
     "psa_last_timings": (C.c_int, [_ctx, C.POINTER(C.c_double)]),
     "psa_k1_stats": (C.c_int, [_ctx, _i64p, C.POINTER(C.c_double)]),
     "psa_debug_phase_table": (C.c_int, [_ctx, _f32p, _f32p, C.c_int64, _i32p, C.c_int64,
                                         C.c_int64, C.c_void_p]),
     "psa_debug_project_only": (C.c_int, [_ctx, C.c_int, _f32p, _f32p, C.c_int64, _i32p,
                                          C.c_int64, C.c_int32, C.c_void_p]),
+    "psa_debug_project_frames": (C.c_int, [_ctx, C.c_int, _f32p, _f32p, C.c_int64, _i32p,
+                                           C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
+    "psa_debug_plane_cache": (C.c_int, [_ctx, _i64p, _i64p]),
     "psa_comm_unique_id": (C.c_int, [C.c_void_p]),
     "psa_comm_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
     "psa_comm_destroy": (C.c_int, [_ctx]),
     "psa_sed_gather": (C.c_int, [_ctx, C.c_int, _i64p, _i64p]),
     "psa_comm_barrier": (C.c_int, [_ctx]),
+    "psa_sed_fs_project": (C.c_int, [_ctx, C.c_int, _f32p, _f32p, C.c_int64, _i32p, C.c_int64, C.c_int32,
+                                     C.c_int64, C.c_int64, C.c_int64]),
+    "psa_sed_fs_exchange": (C.c_int, [_ctx, _i64p, _i64p, _i64p, _i64p]),
+    "psa_sed_fs_read": (C.c_int, [_ctx, C.c_int64, C.c_int64, C.c_void_p]),
+    "psa_sed_fs_write": (C.c_int, [_ctx, C.c_int64, C.c_int64, C.c_void_p]),
+    "psa_sed_fs_finish": (C.c_int, [_ctx, C.c_int32]),
 }
 
 
@@ -220,7 +235,8 @@ class Engine:
         _check(self._lib.psa_create(int(device), C.byref(h)), "psa_create")
         self._h = h
         self.device = int(device)
-        self._resident = {}          # slot -> (weakref to the array, data pointer, shape)
+        self._resident = {}          # slot -> (weakref to the array, data pointer, shape, fingerprint)
+        self._converted = {}         # slot -> (weakref to a non-float32 source, fingerprint, float32 copy)
         # One calculation = upload + project (+ gather) + finalize on ONE context; callers that may
         # race (the reference GUI computes on worker threads) hold this around the sequence.
         self.lock = threading.RLock()
@@ -252,39 +268,89 @@ class Engine:
         return {"name": name.value.decode(), "compute_units": cu.value, "hbm_bytes": mem.value}
 
     # -- trajectory residency --------------------------------------------------------
-    def ensure_resident(self, slot: int, array: np.ndarray):
-        """Upload a (T,N,3) array unless this very array is already in the slot."""
+    @staticmethod
+    def _fingerprint(a: np.ndarray) -> int:
+        """Hash of ~4k elements spread over the array: catches in-place edits of a resident
+        trajectory (scaling, overwriting, loading new frames into the same buffer) without
+        reading it.  Not a proof of equality -- `invalidate()` is the explicit way."""
+        flat = a.reshape(-1) if a.flags.c_contiguous else a.ravel(order="K")
+        step = max(1, flat.size // 4099)
+        return hash(flat[::step][:4099].tobytes())
+
+    def _as_device_layout(self, slot: int, array: np.ndarray) -> np.ndarray:
+        """The array as C-contiguous float32.  A converted copy is kept (per slot) while the
+        source object lives, so that float64 or strided trajectories are not re-converted and
+        re-uploaded on every call."""
         if array.ndim != 3 or array.shape[2] != 3:
             raise ValueError("trajectory array must be (frames, atoms, 3)")
-        a = array if (array.dtype == np.float32 and array.flags.c_contiguous) else \
-            np.ascontiguousarray(array, dtype=np.float32)
+        if array.dtype == np.float32 and array.flags.c_contiguous:
+            return array
+        held = self._converted.get(slot)
+        fp = self._fingerprint(array)
+        if held is not None and held[0]() is array and held[1] == fp:
+            return held[2]
+        conv = np.ascontiguousarray(array, dtype=np.float32)
+        try:
+            self._converted[slot] = (weakref.ref(array), fp, conv)
+        except TypeError:
+            self._converted.pop(slot, None)
+        return conv
+
+    def is_resident(self, slot: int, array: np.ndarray) -> bool:
+        """True if this very array (same object, same buffer, same sampled contents) is what the
+        slot holds."""
+        a = self._as_device_layout(slot, array)
         held = self._resident.get(slot)
-        if (a is array and held is not None and held[0] is not None and held[0]() is array
-                and held[1:] == (a.ctypes.data, a.shape)):
+        return (held is not None and held[0] is not None and held[0]() is a
+                and held[1:3] == (a.ctypes.data, a.shape) and held[3] == self._fingerprint(a))
+
+    def _note_resident(self, slot: int, a: np.ndarray):
+        # a weak reference, not id(): a freed array's id and buffer can be reused
+        try:
+            ref = weakref.ref(a)
+        except TypeError:
+            ref = None
+        self._resident[slot] = (ref, a.ctypes.data, a.shape, self._fingerprint(a))
+
+    def ensure_resident(self, slot: int, array: np.ndarray):
+        """Upload a (T,N,3) array unless this very array is already in the slot."""
+        if self.is_resident(slot, array):
             return
+        a = self._as_device_layout(slot, array)
         T, N = a.shape[0], a.shape[1]
         _check(self._lib.psa_data_upload(self._h, slot, _f32(a), T, N), "psa_data_upload")
-        # a weak reference, not id(): a freed array's id and buffer can be reused
-        self._resident[slot] = (weakref.ref(array) if a is array else None, a.ctypes.data, a.shape)
+        self._note_resident(slot, a)
 
     def invalidate(self, slot: Optional[int] = None):
         """Forget what is resident (call after modifying a trajectory array in place)."""
         if slot is None:
             self._resident.clear()
+            self._converted.clear()
         else:
             self._resident.pop(slot, None)
+            self._converted.pop(slot, None)
 
     def alloc(self, slot: int, T: int, N: int):
         _check(self._lib.psa_data_alloc(self._h, slot, T, N), "psa_data_alloc")
-        self._resident[slot] = (None, None, (T, N, 3))
+        self._resident[slot] = (None, None, (T, N, 3), None)
 
-    def fill_synthetic(self, slot: int, seed: int, amp, comp, ct, st, ca, sa):
+    def fill_synthetic(self, slot: int, seed: int, amp, comp, ct, st, ca, sa, t_offset: int = 0):
+        """ct / st hold the rows of the slot's own frames [t_offset, t_offset + T)."""
         amp = np.ascontiguousarray(amp, np.float32)
         comp = np.ascontiguousarray(comp, np.int32)
         tabs = [np.ascontiguousarray(x, np.float32) for x in (ct, st, ca, sa)]
         _check(self._lib.psa_data_fill_synthetic(
-            self._h, slot, C.c_uint64(seed), len(amp), _f32(amp), comp.ctypes.data_as(_i32p),
+            self._h, slot, C.c_uint64(seed), int(t_offset), len(amp), _f32(amp), comp.ctypes.data_as(_i32p),
             *[_f32(t) for t in tabs]), "psa_data_fill_synthetic")
+
+    def set_option(self, option: int, value: int):
+        _check(self._lib.psa_set_option(self._h, option, int(value)), "psa_set_option")
+
+    def plane_cache(self):
+        """(number of cached split-plane sets, their bytes)"""
+        n, b = C.c_int64(0), C.c_int64(0)
+        _check(self._lib.psa_debug_plane_cache(self._h, C.byref(n), C.byref(b)), "psa_debug_plane_cache")
+        return n.value, b.value
 
     def download(self, slot: int, t0: int, nt: int) -> np.ndarray:
         T, N = self.shape(slot)
@@ -321,13 +387,40 @@ class Engine:
             off.ctypes.data_as(_i64p) if off is not None else None, G, flags),
             "psa_sed_project")
 
+    def project_upload(self, slot, array, mean_pos_all, k_vectors, groups=None, flags=0):
+        """`ensure_resident` + `project` for an array that is not in HBM yet, overlapped: frames are
+        projected as their chunk lands (psa_sed_project_upload)."""
+        a = self._as_device_layout(slot, array)
+        mean = _as_f32(mean_pos_all, (3,))
+        kv = _as_f32(k_vectors, (3,))
+        idx, off, G = pack_groups(groups)
+        self._resident.pop(slot, None)
+        _check(self._lib.psa_sed_project_upload(
+            self._h, slot, _f32(a), a.shape[0], a.shape[1], _f32(mean), _f32(kv), kv.shape[0],
+            idx.ctypes.data_as(_i32p) if idx is not None else None,
+            off.ctypes.data_as(_i64p) if off is not None else None, G, flags), "psa_sed_project_upload")
+        self._note_resident(slot, a)
+
     def finalize(self, T: int, K: int, intensity: bool, fetch: bool = True) -> Optional[np.ndarray]:
+        """(T,K) / (T,K,3) is what the caller expects: the library refuses (PSA_EINVAL) if the
+        result resident on the device has another size."""
         if not fetch:
-            _check(self._lib.psa_sed_finalize(self._h, None), "psa_sed_finalize")
+            _check(self._lib.psa_sed_finalize(self._h, None, 0), "psa_sed_finalize")
             return None
         out = pinned_empty((T, K), np.float32) if intensity else pinned_empty((T, K, 3), np.complex64)
-        _check(self._lib.psa_sed_finalize(self._h, out.ctypes.data_as(C.c_void_p)),
+        _check(self._lib.psa_sed_finalize(self._h, out.ctypes.data_as(C.c_void_p), out.nbytes),
                "psa_sed_finalize")
+        return out
+
+    def single_bin(self, slot, mean_pos_all, k_vector, idx, i_w: int, flags=0) -> np.ndarray:
+        """S[i_w, k, :] of one k-vector and one atom group as (3,) complex64."""
+        mean = _as_f32(mean_pos_all, (3,))
+        kv = np.ascontiguousarray(k_vector, np.float32).reshape(3)
+        ii = None if idx is None else np.ascontiguousarray(idx, np.int32)
+        out = np.empty(3, np.complex64)
+        _check(self._lib.psa_sed_single_bin(
+            self._h, slot, _f32(mean), _f32(kv), ii.ctypes.data_as(_i32p) if ii is not None else None,
+            0 if ii is None else len(ii), flags, int(i_w), out.ctypes.data_as(_f32p)), "psa_sed_single_bin")
         return out
 
     def calculate(self, slot, mean_pos_all, k_vectors, groups=None, flags=0) -> np.ndarray:
@@ -347,12 +440,12 @@ class Engine:
 
     def result_intensity(self, T: int, K: int) -> np.ndarray:
         out = pinned_empty((T, K), np.float32)
-        _check(self._lib.psa_result_intensity(self._h, _f32(out)), "psa_result_intensity")
+        _check(self._lib.psa_result_intensity(self._h, _f32(out), out.nbytes), "psa_result_intensity")
         return out
 
     def result_chiral_phase(self, T: int, K: int, c1: int, c2: int) -> np.ndarray:
         out = pinned_empty((T, K), np.float32)
-        _check(self._lib.psa_result_chiral_phase(self._h, c1, c2, _f32(out)),
+        _check(self._lib.psa_result_chiral_phase(self._h, c1, c2, _f32(out), out.nbytes),
                "psa_result_chiral_phase")
         return out
 
@@ -380,17 +473,24 @@ class Engine:
             out.ctypes.data_as(C.c_void_p)), "psa_debug_phase_table")
         return out
 
-    def debug_project_only(self, slot, mean_pos_all, k_vectors, idx=None, flags=0) -> np.ndarray:
+    def debug_project_only(self, slot, mean_pos_all, k_vectors, idx=None, flags=0, frames=None) -> np.ndarray:
+        """q before the FFT, (K,3,T); `frames=(t_begin, t_count)` projects only those frames (the
+        other columns are zero)."""
         T, N = self.shape(slot)
         mean = _as_f32(mean_pos_all, (3,))
         kv = _as_f32(k_vectors, (3,))
         ii = None if idx is None else np.ascontiguousarray(idx, np.int32)
         n_g = N if ii is None else len(ii)
         out = np.empty((kv.shape[0], 3, T), np.complex64)
-        _check(self._lib.psa_debug_project_only(
-            self._h, slot, _f32(mean), _f32(kv), kv.shape[0],
-            ii.ctypes.data_as(_i32p) if ii is not None else None, n_g, flags,
-            out.ctypes.data_as(C.c_void_p)), "psa_debug_project_only")
+        ip = ii.ctypes.data_as(_i32p) if ii is not None else None
+        if frames is None:
+            _check(self._lib.psa_debug_project_only(
+                self._h, slot, _f32(mean), _f32(kv), kv.shape[0], ip, n_g, flags,
+                out.ctypes.data_as(C.c_void_p)), "psa_debug_project_only")
+        else:
+            _check(self._lib.psa_debug_project_frames(
+                self._h, slot, _f32(mean), _f32(kv), kv.shape[0], ip, n_g, flags, int(frames[0]), int(frames[1]),
+                out.ctypes.data_as(C.c_void_p)), "psa_debug_project_frames")
         return out
 
     # -- k-point sharding ------------------------------------------------------------
@@ -417,3 +517,30 @@ class Engine:
 
     def barrier(self):
         _check(self._lib.psa_comm_barrier(self._h), "psa_comm_barrier")
+
+    # -- frame sharding --------------------------------------------------------------
+    def fs_project(self, slot, mean_pos_all, k_vectors, idx, flags, T_total: int, k_offset: int, k_count: int):
+        """All K k-vectors on the slot's own frames for one atom group -> q_local on the device."""
+        mean = _as_f32(mean_pos_all, (3,))
+        kv = _as_f32(k_vectors, (3,))
+        ii = None if idx is None else np.ascontiguousarray(idx, np.int32)
+        _check(self._lib.psa_sed_fs_project(
+            self._h, slot, _f32(mean), _f32(kv), kv.shape[0], ii.ctypes.data_as(_i32p) if ii is not None else None,
+            0 if ii is None else len(ii), flags, int(T_total), int(k_offset), int(k_count)), "psa_sed_fs_project")
+
+    def fs_exchange(self, t_offsets, t_counts, k_offsets, k_counts):
+        arrs = [np.ascontiguousarray(x, np.int64) for x in (t_offsets, t_counts, k_offsets, k_counts)]
+        _check(self._lib.psa_sed_fs_exchange(self._h, *[a.ctypes.data_as(_i64p) for a in arrs]), "psa_sed_fs_exchange")
+
+    def fs_read(self, k0: int, nk: int, T_local: int) -> np.ndarray:
+        out = np.empty((nk, 3, T_local), np.complex64)
+        _check(self._lib.psa_sed_fs_read(self._h, k0, nk, out.ctypes.data_as(C.c_void_p)), "psa_sed_fs_read")
+        return out
+
+    def fs_write(self, t0: int, block: np.ndarray):
+        block = np.ascontiguousarray(block, np.complex64)
+        _check(self._lib.psa_sed_fs_write(self._h, t0, block.shape[2], block.ctypes.data_as(C.c_void_p)),
+               "psa_sed_fs_write")
+
+    def fs_finish(self, first_group: bool):
+        _check(self._lib.psa_sed_fs_finish(self._h, 1 if first_group else 0), "psa_sed_fs_finish")

@@ -75,6 +75,33 @@ __device__ __forceinline__ void split_component(const f32x4 (&raw)[8], float s, 
     b[1] = cat4(rest[0], rest[1], rest[2], rest[3]);
 }
 
+typedef __attribute__((address_space(3))) unsigned char   lds_u8;
+typedef const __attribute__((address_space(3))) F16x2::v8 lds_cv8;
+typedef const __attribute__((address_space(3))) f32x4     lds_cf32x4;
+
+__device__ __forceinline__ int vs_phys_slot(int s, int row) { return (s & ~7) | ((s & 7) ^ (row & 7)); }
+
+// One LDS-DMA instruction (64 lanes x 16 bytes, global -> LDS at dst + lane * 16), issued from
+// inline assembly: hipcc's wait-count pass books a global_load_lds as a FLAT access that may touch
+// LDS and, while one is pending, turns every LDS-data wait into lgkmcnt(0) and knows no partial
+// vmcnt.  Its completion is awaited explicitly (s_waitcnt vmcnt below); the "memory" clobber keeps
+// LDS accesses from being moved across it.  M0 is a reserved register the compiler re-materialises
+// in front of its own uses.
+__device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_byte_addr) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory");
+}
+// 12 bytes per lane, landing at dst + lane * 16
+__device__ __forceinline__ void lds_dma12(const void* g, unsigned lds_byte_addr) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %0, off" ::"v"(g), "s"(dst) : "memory");
+}
+// 4 bytes per lane, landing at dst + lane * 4
+__device__ __forceinline__ void lds_dma4(const void* g, unsigned lds_byte_addr) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(dst) : "memory");
+}
+
 // index of element (piece, row m, atom a) in the phase-table image: [M block][atom stage]
 // [piece][row][32 atoms]; the four 16-byte slots of a row (8 atoms each) are XOR-swizzled by
 // g((row>>2)&3), g = {0,2,3,1} packed as 0x78, which makes the A-fragment ds_read_b128 conflict-free
@@ -84,5 +111,23 @@ __host__ __device__ inline size_t pf16_tile_index(int piece, int m, int a, int m
     const int    sw = (0x78 >> (2 * ((row >> 2) & 3))) & 3;
     return tile + ((size_t)piece * m_blk + row) * K1_BA + (((al >> 3) ^ sw) << 3) + (al & 7);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Split planes of a trajectory group (k1_planes.hip): the group's data d[t, a, c], already scaled
+// and split into its two float16 pieces, in the image the planes kernel DMAs into LDS --
+//     [frame group of 16][atom stage of 32][component][piece][frame 16][32 atoms]   (float16)
+// i.e. one 1-KiB block per (frame group, stage, component, piece) = one LDS-DMA instruction and,
+// read back with the slot swizzle below, the B fragments of v_mfma_f32_16x16x32_f16 as they
+// stand: lane (frame r, atom octet q) takes 16 bytes at r * 64 + ((q ^ g(r)) << 4).  Same bytes
+// per value as the float32 array (2 + 2).  Frames and atoms past the group's end are zero.
+// ---------------------------------------------------------------------------------------------
+constexpr int PL_BLOCK_ELEMS = 16 * K1_BA;                 // one (component, piece) block: 1 KiB
+constexpr int PL_STAGE_ELEMS = 3 * F16x2::NP * PL_BLOCK_ELEMS;   // 6 KiB per (frame group, stage)
+__host__ __device__ inline int pl_swizzle(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }
+__host__ __device__ inline size_t plane_index(int64_t fg, int stage, int comp, int piece, int r, int al, int n_stage) {
+    return ((size_t)(fg * n_stage + stage) * (3 * F16x2::NP) + (size_t)(comp * F16x2::NP + piece)) * PL_BLOCK_ELEMS +
+           (size_t)r * K1_BA + (size_t)((((al >> 3) ^ pl_swizzle(r)) << 3) + (al & 7));
+}
+inline size_t plane_bytes(int64_t n_fg, int n_stage) { return (size_t)n_fg * n_stage * PL_STAGE_ELEMS * sizeof(_Float16); }
 
 }  // namespace psa

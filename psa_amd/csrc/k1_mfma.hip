@@ -78,7 +78,7 @@ template <int MT, int WM, int WN, bool VDMA, bool DISP>
 __global__ void __launch_bounds__(256, 1)
 k1_mfma_kernel(const float* __restrict__ V, const float* __restrict__ P,
                const int* __restrict__ idx, const float* __restrict__ mean_g,
-               float2* __restrict__ Q, int64_t T, int64_t N_tot, int n_g, int A_pad, int K,
+               float2* __restrict__ Q, int64_t T, int64_t q_stride, int64_t N_tot, int n_g, int A_pad, int K,
                int n_mblk, int n_tblk) {
     using C = K1Cfg<MT, WM, WN>;
     __shared__ __attribute__((aligned(16))) float smem[C::LDS_BYTES / 4];
@@ -297,7 +297,7 @@ k1_mfma_kernel(const float* __restrict__ V, const float* __restrict__ P,
                 if (k < K) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
-                        Q[((int64_t)k * 3 + c) * T + t] = make_float2(acc[mt][c][r0], acc[mt][c][r0 + 1]);
+                        Q[((int64_t)k * 3 + c) * q_stride + t] = make_float2(acc[mt][c][r0], acc[mt][c][r0 + 1]);
                 }
             }
         }
@@ -322,7 +322,7 @@ static int launch_variant(psa_ctx* c, const float* d_v, const float* d_phase, co
     const int64_t grid = ((n_tblk + 7) / 8) * 8 * n_mblk;
     PSA_REQUIRE(grid < (1ll << 31) && n_tblk < (1ll << 31), "projection grid too large");
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, c->stream, d_v, d_phase,
-                       d_idx, d_mean_g, d_q, g.T, g.N_tot, g.n_g, g.A_pad, g.K, n_mblk, (int)n_tblk);
+                       d_idx, d_mean_g, d_q, g.T, g.q_stride, g.N_tot, g.n_g, g.A_pad, g.K, n_mblk, (int)n_tblk);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
 }

@@ -70,37 +70,10 @@ struct K1qCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-typedef __attribute__((address_space(3))) unsigned char   lds_u8;
-typedef const __attribute__((address_space(3))) F16x2::v8 lds_cv8;
-typedef const __attribute__((address_space(3))) f32x4     lds_cf32x4;
-
-__device__ __forceinline__ int vs_phys_slot(int s, int row) { return (s & ~7) | ((s & 7) ^ (row & 7)); }
-
-// One LDS-DMA instruction (64 lanes x 16 bytes, global -> LDS at dst + lane * 16), issued from
-// inline assembly: hipcc's wait-count pass books a global_load_lds as a FLAT access that may touch
-// LDS and, while one is pending, turns every LDS-data wait into lgkmcnt(0) and knows no partial
-// vmcnt.  Its completion is awaited explicitly (s_waitcnt vmcnt below); the "memory" clobber keeps
-// LDS accesses from being moved across it.  M0 is a reserved register the compiler re-materialises
-// in front of its own uses.
-__device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_byte_addr) {
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory");
-}
-// 12 bytes per lane, landing at dst + lane * 16
-__device__ __forceinline__ void lds_dma12(const void* g, unsigned lds_byte_addr) {
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %0, off" ::"v"(g), "s"(dst) : "memory");
-}
-// 4 bytes per lane, landing at dst + lane * 4
-__device__ __forceinline__ void lds_dma4(const void* g, unsigned lds_byte_addr) {
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(dst) : "memory");
-}
-
 template <int MT16_, bool GATHER_>
 __global__ void __launch_bounds__(512, 1)
 k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, const int* __restrict__ idx,
-               float2* __restrict__ Q, int64_t T, int64_t N_tot, int n_g, int n_stage, int K, int n_mblk, int n_tblk,
+               float2* __restrict__ Q, int64_t T, int64_t q_stride, int64_t N_tot, int n_g, int n_stage, int K, int n_mblk, int n_tblk,
                float vscale, float qscale) {
     using C = K1qCfg<MT16_, GATHER_>;
     constexpr bool GATHER = GATHER_;
@@ -333,7 +306,7 @@ k1_pair_kernel(const float* __restrict__ V, const _Float16* __restrict__ Pb, con
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const f32x4 sum = (PSA_K1_EXPERIMENT & 8) ? hi[mt][c] : lo[mt][c];
-                        Q[((int64_t)k * 3 + c) * T + t] = make_float2(sum[2 * pr] * qscale, sum[2 * pr + 1] * qscale);
+                        Q[((int64_t)k * 3 + c) * q_stride + t] = make_float2(sum[2 * pr] * qscale, sum[2 * pr + 1] * qscale);
                     }
                 }
             }
@@ -416,7 +389,7 @@ static int launch_pair_variant(psa_ctx* c, const float* d_v, const void* d_phase
     PSA_REQUIRE(grid < (1ll << 31) && n_tblk < (1ll << 31), "projection grid too large");
     const float qscale = 1.f / (g.vscale * F16x2::P_SCALE);           // powers of two: exact
     hipLaunchKernelGGL((k1_pair_kernel<MT16, GATHER>), dim3((unsigned)grid), dim3(512), 0, c->stream, d_v,
-                       (const _Float16*)d_phase, d_idx, d_q, g.T, g.N_tot, g.n_g, g.A_pad / K1_BA, g.K, n_mblk, (int)n_tblk,
+                       (const _Float16*)d_phase, d_idx, d_q, g.T, g.q_stride, g.N_tot, g.n_g, g.A_pad / K1_BA, g.K, n_mblk, (int)n_tblk,
                        g.vscale, qscale);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;

@@ -1,0 +1,291 @@
+// K1 on pre-split planes: the projection GEMM of k1_pair.hip ("2 x f16", k1_f16.h),
+//     D[m, (c,t)] = sum_a P'[m, a] * d[t, a, c],
+// for a group whose data has been scaled, split into its two float16 pieces and laid out in
+// MFMA-fragment order ONCE (split_planes_kernel below; plane_index in k1_f16.h), instead of on
+// every launch in the inner loop.  What that removes from the stage of k1_pair_kernel: the raw
+// 96-byte de-interleaving LDS reads, 3 VALU operations per value (v_mul, v_cvt_pk_f16, v_fma_mix)
+// and their registers; what it adds: nothing -- the planes have the float32 array's 4 bytes per
+// value, a stage is still 40 KiB of LDS-DMA (16 KiB P' + 4 x 6 KiB V), and the B fragments are
+// ds_read_b128 of the image as it lands.  An index-list or type group is COMPACTED by the split
+// (its atoms become contiguous columns), so every group runs the same row-DMA kernel: no gather
+// variant, no per-stage index traffic.
+//
+// Work decomposition as in k1_pair.hip: eight wavefronts, two per SIMD; wavefront w = 4 h + f owns
+// rows [M_BLK/2 * h, +M_BLK/2) x frames [16 f, 16 f + 16); per 32-atom stage it copies its share of
+// the P' tile and 3 of the 6 blocks of its frame group's V planes (the other row half copies the
+// rest), multiplies from registers while the next stage's fragments are read, and folds its MFMA
+// chains into float32 sums every FOLD stages (f16 MFMA truncation: k1_pair.hip).  RING LDS slots,
+// one s_barrier per stage, counted vmcnt.
+//
+// Frames: the planes hold whole frame groups of 16 (zero-padded); T bounds the stores.  q is
+// written with row stride q_stride so that a launch may cover a frame sub-range of a longer slab.
+#include "k1_f16.h"
+
+namespace psa {
+
+template <int MT16_, int RING_>
+struct K1pCfg {
+    static constexpr int MT16 = MT16_;             // row tiles of 16 per wavefront
+    static constexpr int M_BLK = 32 * MT16;        // 128 / 64 / 32 rows (64 / 32 / 16 k-vectors) per workgroup
+    static constexpr int T_BLK = 64;
+    static constexpr int FOLD = 8;
+    static constexpr int RING = RING_;
+    static constexpr int P_STAGE_BYTES = F16x2::NP * M_BLK * K1_BA * 2;      // 16 / 8 / 4 KiB
+    static constexpr int P_PIECES = P_STAGE_BYTES / 1024;
+    static constexpr int P_DMA = P_PIECES >= 8 ? P_PIECES / 8 : 1;           // per wavefront (4 pieces: waves 4-7 repeat 0-3)
+    static constexpr int V_GROUP_BYTES = PL_STAGE_ELEMS * 2;                 // 6 KiB
+    static constexpr int V_DMA = 3;
+    static constexpr int STAGE_BYTES = P_STAGE_BYTES + 4 * V_GROUP_BYTES;    // 40 / 32 / 28 KiB
+    static constexpr int LDS_BYTES = RING * STAGE_BYTES;
+    static constexpr int BATCH = P_DMA + V_DMA;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(RING >= 3, "stage s+1 read while s+2 .. s+RING travel");
+};
+
+template <int MT16_, int RING_>
+__global__ void __launch_bounds__(512, 1)
+k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict__ Pb, float2* __restrict__ Q,
+                 int64_t T, int64_t q_stride, int n_fg, int n_stage, int K, int n_mblk, int n_tblk, float qscale) {
+    using C = K1pCfg<MT16_, RING_>;
+    using PR = F16x2;
+    using E8 = PR::v8;
+    constexpr int NP = PR::NP, MT16 = C::MT16;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
+    const unsigned lds0 = (unsigned)(size_t)(lds_u8*)smem;
+
+    // XCD-aware block map (k1_pair.hip): blocks b and b+8 share an XCD and get the M blocks of one
+    // frame tile, so the tile's planes come from HBM once.
+    const int b  = blockIdx.x;
+    const int r8 = b >> 3;
+    const int mb = r8 % n_mblk;
+    const int tb = (r8 / n_mblk) * 8 + (b & 7);
+    if (tb >= n_tblk) return;
+
+    const int     tid = threadIdx.x, lane = tid & 63;
+    const int     w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int     wh = w >> 2, wf = w & 3;
+    const int     r16 = lane & 15, q = lane >> 4;
+    const int64_t t0 = (int64_t)tb * C::T_BLK + wf * 16;
+    const int     last = n_stage - 1;
+    int           fg = tb * 4 + wf;                                  // frame group (past the end: the last one, never stored)
+    if (fg >= n_fg) fg = n_fg - 1;
+
+    // ---- DMA sources: this wavefront's blocks of the V planes and of the P' tile ----------------
+    const unsigned char* vp = reinterpret_cast<const unsigned char*>(planes) +
+                              (size_t)fg * n_stage * C::V_GROUP_BYTES + 1024 * (wh * C::V_DMA) + 16 * lane;
+    const int            pw = C::P_PIECES >= 8 ? w * C::P_DMA : (w & 3);
+    const unsigned char* pp = reinterpret_cast<const unsigned char*>(Pb) + (size_t)mb * n_stage * C::P_STAGE_BYTES +
+                              1024 * pw + 16 * lane;
+    auto dma_stage = [&](int st, int slot) {
+        const int      sc = st < last ? st : last;
+        const unsigned dst = lds0 + slot * C::STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < C::P_DMA; ++i)
+            lds_dma16(pp + (size_t)sc * C::P_STAGE_BYTES + 1024 * i, dst + 1024 * (pw + i));
+        const unsigned vdst = dst + C::P_STAGE_BYTES + wf * C::V_GROUP_BYTES + 1024 * (wh * C::V_DMA);
+#pragma unroll
+        for (int j = 0; j < C::V_DMA; ++j) lds_dma16(vp + (size_t)sc * C::V_GROUP_BYTES + 1024 * j, vdst + 1024 * j);
+    };
+
+    // ---- LDS read addresses: both images use the 64-byte rows / swizzled 16-byte slots of k1_f16.h
+    const int      gsw = pl_swizzle(r16);
+    const unsigned p_lane = lds0 + (wh * (C::M_BLK / 2) + r16) * (K1_BA * 2) + ((q ^ gsw) << 4);
+    const unsigned v_lane = lds0 + C::P_STAGE_BYTES + wf * C::V_GROUP_BYTES + r16 * (K1_BA * 2) + ((q ^ gsw) << 4);
+    E8    a[NP][MT16];
+    E8    bs[2][3][NP];                            // B fragments of stage k: bs[k & 1][component][piece]
+    f32x4 hi[MT16][3], lo[MT16][3];                // the running MFMA chains / the float32 sums
+    auto  read_a_tile = [&](int mt, int slot) {
+        const unsigned base = p_lane + slot * C::STAGE_BYTES;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            a[p][mt] = *reinterpret_cast<lds_cv8*>((const lds_u8*)(size_t)(base + (p * C::M_BLK + mt * 16) * 64));
+    };
+    auto read_b = [&](int par, int slot) {
+        const unsigned base = v_lane + slot * C::STAGE_BYTES;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                bs[par][c][p] = *reinterpret_cast<lds_cv8*>((const lds_u8*)(size_t)(base + (c * NP + p) * 1024));
+    };
+#pragma unroll
+    for (int mt = 0; mt < MT16; ++mt)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            hi[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            lo[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+    // ---- prologue: stages 0 .. RING-1 in flight; stage 0 into registers --------------------------
+#pragma unroll
+    for (int k = 0; k < C::RING; ++k) dma_stage(k, k);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((C::RING - 1) * C::BATCH) : "memory");      // stage 0 landed
+    read_b(0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT16; ++mt) read_a_tile(mt, 0);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((C::RING - 2) * C::BATCH) : "memory");   // stage 1 landed, slot 0 read
+
+    auto mfma_tile = [&](int mt, int par, bool restart) {
+        f32x4 ch[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            ch[c] = PR::mma(a[1][mt], bs[par][c][0], restart ? f32x4{0.f, 0.f, 0.f, 0.f} : hi[mt][c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ch[c] = PR::mma(a[0][mt], bs[par][c][1], ch[c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) hi[mt][c] = PR::mma(a[0][mt], bs[par][c][0], ch[c]);
+    };
+    // One stage: slot holds stage s (in registers already), slot1 stage s+1 (landed).  The DMA of
+    // stage s+RING goes into slot; the B fragments of stage s+1 are read at the top, each row tile's
+    // A fragments right behind the MFMAs that consumed the old ones.
+    auto stage = [&](auto par_c, auto restart_c, int s, int slot) {
+        constexpr int  par = decltype(par_c)::value;
+        constexpr bool restart = decltype(restart_c)::value;
+        const int      slot1 = slot == C::RING - 1 ? 0 : slot + 1;
+        dma_stage(s + C::RING, slot);
+        read_b(par ^ 1, slot1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT16; ++mt) {
+            mfma_tile(mt, par, restart);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a_tile(mt, slot1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // own blocks of stage s+2 landed (younger batches stay in flight), own LDS reads returned
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((C::RING - 2) * C::BATCH) : "memory");
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    int  slot = 0;                                     // s % RING
+    auto next_slot = [&]() { slot = slot == C::RING - 1 ? 0 : slot + 1; };
+    for (int s = 0; s < n_stage;) {                    // n_stage is even; a chain is an even number of stages
+        const int len = n_stage - s < C::FOLD ? n_stage - s : C::FOLD;
+        stage(I0{}, std::true_type{}, s, slot);
+        next_slot();
+        stage(I1{}, std::false_type{}, s + 1, slot);
+        next_slot();
+        for (int i = 2; i < len; i += 2) {
+            stage(I0{}, std::false_type{}, s + i, slot);
+            next_slot();
+            stage(I1{}, std::false_type{}, s + i + 1, slot);
+            next_slot();
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT16; ++mt)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) lo[mt][c] += hi[mt][c];
+        s += len;
+    }
+    // the clamped prefetches of stages >= n_stage are still in flight: let them land before the
+    // workgroup's LDS is handed to the next one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // epilogue: register j of lane (r16, q) is row 4q + j, column r16 of its 16x16 tile; rows
+    // 2p, 2p+1 are the cos / sin rows of one k -> one complex64 per lane and register pair
+    const int     m0 = mb * C::M_BLK + wh * (C::M_BLK / 2);
+    const int64_t t = t0 + r16;
+    if (t < T) {
+#pragma unroll
+        for (int mt = 0; mt < MT16; ++mt) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int k = (m0 + mt * 16 + 4 * q + 2 * pr) >> 1;
+                if (k < K) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        Q[((int64_t)k * 3 + c) * q_stride + t] =
+                            make_float2(lo[mt][c][2 * pr] * qscale, lo[mt][c][2 * pr + 1] * qscale);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The split itself: d (float32, native (T, N, 3) rows; atoms through an index list if there is
+// one) -> the two scaled float16 planes in fragment order.  One pass: 12 bytes read and 12 written
+// per (frame, atom).  A block of three wavefronts handles one (frame group, stage) tile: the 16 x 96
+// floats go through LDS (coalesced reads along the row), then wavefront c converts component c,
+// each lane one 8-atom fragment, written as two 16-byte stores.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(192)
+split_planes_kernel(const float* __restrict__ x, const int* __restrict__ idx, _Float16* __restrict__ planes, int64_t T,
+                    int64_t N_tot, int n_g, int n_stage, int64_t n_fg, float vscale) {
+    __shared__ float raw[16][100];
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int64_t fg = blockIdx.y; fg < n_fg; fg += gridDim.y) {
+        const int64_t t0 = fg * 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int     e = tid + 192 * j;
+            const int     row = e / 96, col = e - row * 96;
+            const int     al = col / 3, comp = col - 3 * al;
+            const int     pos = s * K1_BA + al;
+            const int64_t t = t0 + row;
+            float         v = 0.f;
+            if (t < T && pos < n_g) {
+                const int64_t atom = idx ? idx[pos] : pos;
+                v = x[(t * N_tot + atom) * 3 + comp];
+            }
+            raw[row][col] = v;
+        }
+        __syncthreads();
+        const int comp = tid >> 6, r = (tid >> 2) & 15, oct = tid & 3;
+        F16x2::v2 lead[4], rest[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            split_pair(raw[r][(8 * oct + 2 * i) * 3 + comp], raw[r][(8 * oct + 2 * i + 1) * 3 + comp], vscale, lead[i],
+                       rest[i]);
+        const size_t o = plane_index(fg, s, comp, 0, r, 8 * oct, n_stage);
+        *reinterpret_cast<F16x2::v8*>(planes + o) = cat4(lead[0], lead[1], lead[2], lead[3]);
+        *reinterpret_cast<F16x2::v8*>(planes + o + PL_BLOCK_ELEMS) = cat4(rest[0], rest[1], rest[2], rest[3]);
+        __syncthreads();
+    }
+}
+
+int launch_split_planes(psa_ctx* c, const float* d_x, const int* d_idx, void* d_planes, int64_t T, int64_t N_tot, int n_g,
+                        int A_pad, float vscale) {
+    const int     n_stage = A_pad / K1_BA;
+    const int64_t n_fg = (T + 15) / 16;
+    PSA_REQUIRE(n_stage > 0 && n_fg > 0 && vscale > 0.f, "bad split geometry");
+    dim3 grid((unsigned)n_stage, (unsigned)(n_fg < 4096 ? n_fg : 4096));
+    hipLaunchKernelGGL(split_planes_kernel, grid, dim3(192), 0, c->stream, d_x, d_idx, (_Float16*)d_planes, T, N_tot, n_g,
+                       n_stage, n_fg, vscale);
+    PSA_HIP_CHECK(hipGetLastError());
+    return PSA_OK;
+}
+
+// rows per workgroup for a k-list: 128 beyond 32 k-vectors, 64 for 17..32, 32 up to 16
+int k1_planes_block_rows(int K) { return 2 * K <= 32 ? 32 : 2 * K <= 64 ? 64 : 128; }
+
+template <int MT16, int RING>
+static int launch_planes_variant(psa_ctx* c, const void* d_planes, const void* d_phase, float2* d_q, const ProjGeom& g,
+                                 int64_t n_fg) {
+    using C = K1pCfg<MT16, RING>;
+    const int     n_mblk = g.M_pad / C::M_BLK;
+    const int64_t n_tblk = (g.T + C::T_BLK - 1) / C::T_BLK;
+    const int64_t grid = ((n_tblk + 7) / 8) * 8 * n_mblk;
+    PSA_REQUIRE(grid < (1ll << 31) && n_tblk < (1ll << 29) && n_fg < (1ll << 31), "projection grid too large");
+    const float qscale = 1.f / (g.vscale * F16x2::P_SCALE);           // powers of two: exact
+    hipLaunchKernelGGL((k1_planes_kernel<MT16, RING>), dim3((unsigned)grid), dim3(512), 0, c->stream,
+                       (const _Float16*)d_planes, (const _Float16*)d_phase, d_q, g.T, g.q_stride, (int)n_fg,
+                       g.A_pad / K1_BA, g.K, n_mblk, (int)n_tblk, qscale);
+    PSA_HIP_CHECK(hipGetLastError());
+    return PSA_OK;
+}
+
+// d_planes: the group's planes from the frame group that holds the launch's first frame on
+// (g.T frames from there, n_fg frame groups available)
+int launch_k1_planes(psa_ctx* c, const void* d_planes, const void* d_phase, float2* d_q, const ProjGeom& g, int64_t n_fg) {
+    PSA_REQUIRE((g.m_blk == 128 || g.m_blk == 64 || g.m_blk == 32) && g.M_pad % g.m_blk == 0,
+                "planes kernel needs 32-, 64- or 128-row M blocks");
+    PSA_REQUIRE(g.A_pad % (2 * K1_BA) == 0 && g.A_pad > 0, "planes kernel needs the atom axis padded to %d", 2 * K1_BA);
+    PSA_REQUIRE(g.vscale > 0.f && n_fg * 16 >= g.T, "planes do not cover the launch");
+    if (g.m_blk == 128) return launch_planes_variant<4, 3>(c, d_planes, d_phase, d_q, g, n_fg);
+    if (g.m_blk == 64) return launch_planes_variant<2, 4>(c, d_planes, d_phase, d_q, g, n_fg);
+    return launch_planes_variant<1, 4>(c, d_planes, d_phase, d_q, g, n_fg);
+}
+
+}  // namespace psa

@@ -132,7 +132,7 @@ __device__ __forceinline__ void split_component(const f32x4 (&raw)[N], bf16x8& b
 template <int MT16, bool GATHER>
 __global__ void __launch_bounds__(256, (K1sCfg<MT16, GATHER>::WG_PER_CU))
 k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb, const int* __restrict__ idx,
-                float2* __restrict__ Q, int64_t T, int64_t N_tot, int n_g, int A_pad, int K,
+                float2* __restrict__ Q, int64_t T, int64_t q_stride, int64_t N_tot, int n_g, int A_pad, int K,
                 int n_mblk, int n_tblk) {
     using C = K1sCfg<MT16, GATHER>;
     // ring slot r: [V tile: T_BLK rows x 96 float32][P' tile: 3 planes x M_BLK rows x 32 bf16]
@@ -436,7 +436,7 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb, cons
                 if (k < K) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
-                        Q[((int64_t)k * 3 + c) * T + t] =
+                        Q[((int64_t)k * 3 + c) * q_stride + t] =
                             make_float2(hi[mt][c][2 * pr] + lo[mt][c][2 * pr],
                                         hi[mt][c][2 * pr + 1] + lo[mt][c][2 * pr + 1]);
                 }
@@ -509,11 +509,11 @@ static int launch_split_variant(psa_ctx* c, const float* d_v, const void* d_phas
     const bool contiguous = d_idx == nullptr && g.N_tot % 4 == 0 && g.n_g == g.N_tot;
     if (contiguous)
         hipLaunchKernelGGL((k1_split_kernel<MT16, false>), dim3((unsigned)grid), dim3(256), 0, c->stream, d_v,
-                           (const __bf16*)d_phase, d_idx, d_q, g.T, g.N_tot, g.n_g, g.A_pad, g.K, n_mblk,
+                           (const __bf16*)d_phase, d_idx, d_q, g.T, g.q_stride, g.N_tot, g.n_g, g.A_pad, g.K, n_mblk,
                            (int)n_tblk);
     else
         hipLaunchKernelGGL((k1_split_kernel<MT16, true>), dim3((unsigned)grid), dim3(256), 0, c->stream, d_v,
-                           (const __bf16*)d_phase, d_idx, d_q, g.T, g.N_tot, g.n_g, g.A_pad, g.K, n_mblk,
+                           (const __bf16*)d_phase, d_idx, d_q, g.T, g.q_stride, g.N_tot, g.n_g, g.A_pad, g.K, n_mblk,
                            (int)n_tblk);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;

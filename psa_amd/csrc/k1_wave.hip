@@ -21,7 +21,7 @@ template <bool DISP>
 __global__ void __launch_bounds__(256)
 k1_wave_kernel(const float* __restrict__ V, const float* __restrict__ P,
                const int* __restrict__ idx, const float* __restrict__ mean_g,
-               float2* __restrict__ Q, int64_t T, int64_t N_tot, int n_g, int A_pad, int K, int m_blk) {
+               float2* __restrict__ Q, int64_t T, int64_t q_stride, int64_t N_tot, int n_g, int A_pad, int K, int m_blk) {
     __shared__ float vs[WK_ATOMS * 3];
     const int64_t t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -83,7 +83,7 @@ k1_wave_kernel(const float* __restrict__ V, const float* __restrict__ P,
                 i += __shfl_down(i, off, 64);
             }
             const int k = k0 + j;
-            if (lane == 0 && k < K) Q[((int64_t)k * 3 + c) * T + t] = make_float2(r, i);
+            if (lane == 0 && k < K) Q[((int64_t)k * 3 + c) * q_stride + t] = make_float2(r, i);
         }
 }
 
@@ -94,10 +94,10 @@ int launch_k1_wave(psa_ctx* c, const float* d_v, const float* d_phase, const int
     dim3 grid((unsigned)g.T, (unsigned)ky);
     if (displacements)
         hipLaunchKernelGGL(k1_wave_kernel<true>, grid, dim3(256), 0, c->stream, d_v, d_phase, d_idx,
-                           d_mean_g, d_q, g.T, g.N_tot, g.n_g, g.A_pad, g.K, g.m_blk);
+                           d_mean_g, d_q, g.T, g.q_stride, g.N_tot, g.n_g, g.A_pad, g.K, g.m_blk);
     else
         hipLaunchKernelGGL(k1_wave_kernel<false>, grid, dim3(256), 0, c->stream, d_v, d_phase, d_idx,
-                           d_mean_g, d_q, g.T, g.N_tot, g.n_g, g.A_pad, g.K, g.m_blk);
+                           d_mean_g, d_q, g.T, g.q_stride, g.N_tot, g.n_g, g.A_pad, g.K, g.m_blk);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
 }

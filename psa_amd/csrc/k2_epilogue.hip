@@ -7,6 +7,7 @@
 //   transpose_f32         I[k,w] -> out[w,k]                         ref: :327
 //   result_intensity      sum_c |out[w,k,c]|^2                       ref: core/sed.py:22-24
 //   result_chiral_c       folded phase difference of two components  ref: :344-350
+//   dft_bin               one frequency bin of FFT_t(q)/T                 ref: :83-84 as used by :494-499
 #include "psa_ctx.h"
 
 namespace psa {
@@ -163,6 +164,52 @@ int launch_result_chiral_c(psa_ctx* c, const float2* d_out, float* d_phase, int6
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(result_chiral_c_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_out,
                        d_phase, n_tk, c1, c2);
+    PSA_HIP_CHECK(hipGetLastError());
+    return PSA_OK;
+}
+
+// One frequency bin of the time FFT of a single k-vector's projection q (3, T):
+//   S_c = (1/T) sum_t q[c,t] exp(-2 pi i bin t / T)
+// -- all that iSED consumes of a group's spectrum (sed_calculator.py:483, :494-499).  The twiddle
+// angle is reduced exactly in integers (bin * t mod T) and evaluated in double, the sum is kept
+// in double: the result is the correctly rounded value the float32 FFT approximates.
+__global__ void __launch_bounds__(1024)
+dft_bin_kernel(const float2* __restrict__ q, int64_t T, int64_t bin, float2* __restrict__ out3) {
+    __shared__ double red[16][6];
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const double w = -6.283185307179586476925286766559 / (double)T;
+    for (int64_t t = threadIdx.x; t < T; t += 1024) {
+        const int64_t m = (int64_t)(((unsigned __int128)(uint64_t)bin * (uint64_t)t) % (uint64_t)T);
+        double sn, cs;
+        sincos(w * (double)m, &sn, &cs);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float2 v = q[c * T + t];
+            acc[2 * c] += (double)v.x * cs - (double)v.y * sn;
+            acc[2 * c + 1] += (double)v.x * sn + (double)v.y * cs;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0)
+        for (int j = 0; j < 6; ++j) red[wave][j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double re = 0, im = 0;
+        for (int k = 0; k < 16; ++k) {
+            re += red[k][2 * threadIdx.x];
+            im += red[k][2 * threadIdx.x + 1];
+        }
+        out3[threadIdx.x] = make_float2((float)(re / (double)T), (float)(im / (double)T));
+    }
+}
+
+int launch_dft_bin(psa_ctx* c, const float2* d_q, int64_t T, int64_t bin, float2* d_out3) {
+    hipLaunchKernelGGL(dft_bin_kernel, dim3(1), dim3(1024), 0, c->stream, d_q, T, bin, d_out3);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
 }

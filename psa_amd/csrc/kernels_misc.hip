@@ -84,7 +84,7 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 }
 
 __global__ void __launch_bounds__(256)
-fill_synthetic_kernel(float* __restrict__ v, int64_t T, int64_t N, uint64_t seed, int n_modes,
+fill_synthetic_kernel(float* __restrict__ v, int64_t T, int64_t N, uint64_t seed, int64_t t_offset, int n_modes,
                       const float* __restrict__ amp, const int* __restrict__ comp,
                       const float* __restrict__ ct, const float* __restrict__ st,
                       const float* __restrict__ ca, const float* __restrict__ sa) {
@@ -95,7 +95,9 @@ fill_synthetic_kernel(float* __restrict__ v, int64_t T, int64_t N, uint64_t seed
         const int64_t ta = i / 3;
         const int     cc = (int)(i - 3 * ta);
         const int64_t t = ta / N, a = ta - t * N;
-        const uint64_t h = splitmix64((uint64_t)i ^ key);
+        // the counter is the element's index in the WHOLE trajectory: a rank that holds frames
+        // [t_offset, t_offset + T) generates exactly its slice of the one synthetic array
+        const uint64_t h = splitmix64((uint64_t)(i + t_offset * N * 3) ^ key);
         const int s = (int)(h & 0xFFFF) + (int)((h >> 16) & 0xFFFF) + (int)((h >> 32) & 0xFFFF) +
                       (int)(h >> 48);
         float val = __fmul_rn((float)(s - 131070), 1.0f / 37837.0f);
@@ -110,7 +112,7 @@ fill_synthetic_kernel(float* __restrict__ v, int64_t T, int64_t N, uint64_t seed
     }
 }
 
-int launch_fill_synthetic(psa_ctx* c, float* d_v, int64_t T, int64_t N, uint64_t seed, int n_modes,
+int launch_fill_synthetic(psa_ctx* c, float* d_v, int64_t T, int64_t N, uint64_t seed, int64_t t_offset, int n_modes,
                           const float* d_amp, const int* d_comp, const float* d_ct,
                           const float* d_st, const float* d_ca, const float* d_sa) {
     const int64_t total = T * N * 3;
@@ -118,7 +120,7 @@ int launch_fill_synthetic(psa_ctx* c, float* d_v, int64_t T, int64_t N, uint64_t
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(fill_synthetic_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_v, T,
-                       N, seed, n_modes, d_amp, d_comp, d_ct, d_st, d_ca, d_sa);
+                       N, seed, t_offset, n_modes, d_amp, d_comp, d_ct, d_st, d_ca, d_sa);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
 }

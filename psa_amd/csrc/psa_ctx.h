@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -119,15 +120,41 @@ inline size_t p_table_floats(int M_pad, int A_pad) { return (size_t)M_pad * (A_p
 
 // geometry of one projection launch (see k1_mfma.hip)
 struct ProjGeom {
-    int64_t T = 0;        // frames
+    int64_t T = 0;        // frames of this launch
+    int64_t q_stride = 0; // frames per row of the q slab the launch writes into (>= T)
     int64_t N_tot = 0;    // atoms in the resident array
     int     n_g = 0;      // atoms in this group
     int     A_pad = 0;    // n_g rounded up to the atom stage (32)
     int     K = 0;        // k-vectors (rows of the output)
     int     M_pad = 0;    // 2K rounded up to the variant's M block
     int     m_blk = 0;    // rows of P per workgroup (variant)
-    int     split = 0;    // 0: float32 kernels; 2: "2 x f16" kernel (k1_pair.hip); 3: "3 x bf16" (k1_split.hip)
+    int     split = 0;    // 0: float32 kernels; 2: "2 x f16" kernel (k1_pair.hip); 3: "3 x bf16" (k1_split.hip);
+                          // 4: "2 x f16" from the group's cached split planes (k1_planes.hip)
     float   vscale = 0.f; // split == 2: power of two applied to d (from the slot's largest magnitude)
+};
+
+// A group's data as cached split planes (k1_f16.h plane_index): built from one generation of one
+// slot, for one atom list (or all atoms), with one power-of-two scale.
+struct PlaneSet {
+    DevBuf               buf;
+    int                  slot = 0;
+    uint64_t             generation = 0;
+    bool                 all_atoms = true;
+    std::vector<int32_t> idx;            // the atom list (compacted order), empty when all_atoms
+    uint64_t             idx_hash = 0;
+    int64_t              T = 0, n_fg = 0;
+    int                  n_g = 0, A_pad = 0;
+    float                vscale = 0.f;
+    uint64_t             last_use = 0;
+};
+
+// page-locked staging buffers + copy stream of the host->device pipeline (psa_data_upload,
+// psa_sed_project_upload)
+struct Stager {
+    void*       pin[2] = {nullptr, nullptr};
+    size_t      cap = 0;
+    hipEvent_t  freed[2] = {nullptr, nullptr};   // the H2D copy out of pin[i] has finished
+    hipStream_t copy_stream = nullptr;
 };
 
 }  // namespace psa
@@ -150,6 +177,18 @@ struct psa_ctx {
 
     // per-call scratch
     psa::DevBuf d_kvec, d_mean_all, d_idx, d_mean_g, d_phase, d_qwork, d_fft_work, d_tables, d_absmax;
+    psa::DevBuf d_qrows, d_stage, d_bin;      // frame sharding: my rows before the FFT / all-to-all landing zone; one DFT bin
+
+    // cached split planes (PSA_OPT_PLANES*)
+    std::vector<std::unique_ptr<psa::PlaneSet>> planes;
+    std::vector<uint64_t> seen_groups;        // hashes of index-list groups projected once already
+    uint64_t plane_tick = 0, plane_call_mark = 0;   // sets touched since the mark belong to the call in progress
+    int64_t  opt_planes = 1, opt_planes_budget = 0, opt_planes_eager = 0, opt_planes_min_k = 17;
+    psa::Stager stager;
+
+    // frame sharding (psa_sed_fs_*): geometry of the group in flight
+    int64_t fs_T_total = 0, fs_T_local = 0, fs_K_total = 0, fs_rows_k0 = 0, fs_rows_nk = 0;
+    bool    fs_intensity = false;
     // results
     psa::DevBuf d_slab;      // k-major: (K_total,3,T) c64  or (K_total,T) f32
     psa::DevBuf d_out;       // reference layout: (T,K_total,3) c64 or (T,K_total) f32
@@ -174,7 +213,7 @@ int launch_phase_table(psa_ctx* c, const float* d_kvec, const float* d_mean_all,
                        float* d_phase, const ProjGeom& g);
 int launch_gather_mean(psa_ctx* c, const float* d_mean_all, const int* d_idx, float* d_mean_g,
                        const ProjGeom& g);
-int launch_fill_synthetic(psa_ctx* c, float* d_v, int64_t T, int64_t N, uint64_t seed, int n_modes,
+int launch_fill_synthetic(psa_ctx* c, float* d_v, int64_t T, int64_t N, uint64_t seed, int64_t t_offset, int n_modes,
                           const float* d_amp, const int* d_comp, const float* d_ct,
                           const float* d_st, const float* d_ca, const float* d_sa);
 int launch_mean_over_frames(psa_ctx* c, const float* d_x, int64_t T, int64_t N, float* d_mean);
@@ -209,7 +248,15 @@ int    launch_phase_table_f16(psa_ctx* c, const float* d_kvec, const float* d_me
 int    launch_k1_pair(psa_ctx* c, const float* d_v, const void* d_phase, const int* d_idx, float2* d_q,
                       const ProjGeom& g);
 
+// --- k1_planes.hip ("2 x f16" from cached split planes: every kind of group)
+int    k1_planes_block_rows(int K);
+int    launch_split_planes(psa_ctx* c, const float* d_x, const int* d_idx, void* d_planes, int64_t T, int64_t N_tot,
+                           int n_g, int A_pad, float vscale);
+int    launch_k1_planes(psa_ctx* c, const void* d_planes, const void* d_phase, float2* d_q, const ProjGeom& g,
+                        int64_t n_fg);
+
 // --- k2_epilogue.hip
+int launch_dft_bin(psa_ctx* c, const float2* d_q, int64_t T, int64_t bin, float2* d_out3);
 int launch_scale_transpose_c64(psa_ctx* c, const float2* d_slab, float2* d_out, int64_t T, int64_t K);
 int launch_intensity_accumulate(psa_ctx* c, const float2* d_q, float* d_slab_rows, int64_t T,
                                 int64_t K_local, bool first_group);

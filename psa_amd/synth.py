@@ -107,10 +107,15 @@ def velocities_block(spec: SyntheticSpec, tables, t0: int, nt: int) -> np.ndarra
     return v
 
 
-def fill_device(engine, slot: int, spec: SyntheticSpec, tables) -> None:
-    """Generate the same array directly in HBM."""
-    engine.alloc(slot, spec.n_frames, spec.n_atoms)
-    engine.fill_synthetic(slot, spec.seed, *tables)
+def fill_device(engine, slot: int, spec: SyntheticSpec, tables, t_begin: int = 0, t_count: int = None) -> None:
+    """Generate the same array directly in HBM -- or only its frames [t_begin, t_begin + t_count)
+    (a frame-sharded rank holds just its slice)."""
+    amp, comp, ct, st, ca, sa = tables
+    if t_count is None:
+        t_count = spec.n_frames - t_begin
+    engine.alloc(slot, t_count, spec.n_atoms)
+    engine.fill_synthetic(slot, spec.seed, amp, comp, ct[:, t_begin:t_begin + t_count], st[:, t_begin:t_begin + t_count],
+                          ca, sa, t_offset=t_begin)
 
 
 def reciprocal_step(cells) -> np.ndarray:
