@@ -273,9 +273,10 @@ class Engine:
         """Hash of ~4k elements spread over the array: catches in-place edits of a resident
         trajectory (scaling, overwriting, loading new frames into the same buffer) without
         reading it.  Not a proof of equality -- `invalidate()` is the explicit way."""
-        flat = a.reshape(-1) if a.flags.c_contiguous else a.ravel(order="K")
-        step = max(1, flat.size // 4099)
-        return hash(flat[::step][:4099].tobytes())
+        if a.size == 0:
+            return 0
+        lin = np.arange(0, a.size, max(1, a.size // 4099), dtype=np.int64)[:4099]
+        return hash(a[np.unravel_index(lin, a.shape)].tobytes())     # a gather: never copies the array
 
     def _as_device_layout(self, slot: int, array: np.ndarray) -> np.ndarray:
         """The array as C-contiguous float32.  A converted copy is kept (per slot) while the

@@ -9,6 +9,12 @@ where the arithmetic runs: the reference's `_calculate_sed_for_group` (:58-84, N
 einsum + pocketfft) is replaced by libpsa_hip.so (phase table -> split-precision f16-MFMA projection, fp32-equivalent ->
 batched rocFFT -> epilogue) through `psa_amd._hip.Engine`.  There is no CPU path here.
 
+Residency: the first `calculate` uploads the velocity array (positions with
+`use_displacements=True`) to HBM -- projecting the frames of each chunk as it lands -- and later
+calls reuse it.  "The same array" is decided by object identity plus a hash of ~4000 sampled
+elements, so in-place edits are normally noticed; after editing a trajectory array in place call
+`calculator.invalidate()` to be certain (the reference re-reads the array on every call).
+
 `calculate_kpath_sed` / `calculate_kgrid_sed` / `calculate_chiral_sed` are the composites
 the reference's README names (README.md:100-140) and its GUI implements privately
 (src/psa/gui/psa_gui.py:923-1017, :2099-2247): k generator -> `calculate` -> optional
@@ -99,6 +105,14 @@ class SEDCalculator:
             self._engine.close()
         self._engine = None
 
+    def invalidate(self):
+        """Forget everything cached about the trajectory arrays -- the copies resident in HBM and
+        the mean positions.  Call it after modifying `traj.positions` / `traj.velocities` in
+        place; the next `calculate` uploads afresh."""
+        self._mean_cache = None
+        if self._engine is not None:
+            self._engine.invalidate()
+
     def _mean_positions(self) -> np.ndarray:
         """np.mean(positions, axis=0, dtype=float32) exactly as the reference (:205), cached per
         positions array because it is a full pass over (T,N,3).  In displacement mode the
@@ -106,15 +120,17 @@ class SEDCalculator:
         the frames in the same order into a float32 accumulator: bit-identical); otherwise it
         is the reference's own NumPy call on the host."""
         pos = self.traj.positions
-        if self._mean_cache is not None and self._mean_cache[0]() is pos:
+        stamp = _hip.Engine._fingerprint(pos) if isinstance(pos, np.ndarray) and pos.size else None
+        if self._mean_cache is not None and self._mean_cache[0]() is pos and self._mean_cache[2] == stamp:
             return self._mean_cache[1]
-        if self.use_displacements:
+        frame_sharded = self._shard is not None and self._shard.nranks > 1 and self._shard.mode != "k"
+        if self.use_displacements and not frame_sharded:
             self.engine.ensure_resident(_hip.SLOT_POSITIONS, pos)
             mean = self.engine.mean_positions(_hip.SLOT_POSITIONS)
-        else:
+        else:               # (a frame-sharded rank holds only its own frames in HBM)
             mean = np.mean(pos, axis=0, dtype=np.float32)
         try:
-            self._mean_cache = (weakref.ref(pos), mean)
+            self._mean_cache = (weakref.ref(pos), mean, stamp)
         except TypeError:
             self._mean_cache = None
         return mean
@@ -139,12 +155,14 @@ class SEDCalculator:
             flags |= _hip.F_INTENSITY
         eng = self.engine
         with eng.lock:                       # project + finalize must not interleave across threads
-            eng.ensure_resident(slot, data)
             K = len(k_vectors)
             T = self.traj.n_frames
             if self._shard is not None and self._shard.nranks > 1:
-                return self._shard.run(slot, mean_pos_all, k_vectors, groups, flags, T, fetch)
-            eng.project(slot, mean_pos_all, k_vectors, groups, flags)
+                return self._shard.run(slot, data, mean_pos_all, k_vectors, groups, flags, T, fetch)
+            if eng.is_resident(slot, data):
+                eng.project(slot, mean_pos_all, k_vectors, groups, flags)
+            else:                            # first call on this array: upload and project, overlapped
+                eng.project_upload(slot, data, mean_pos_all, k_vectors, groups, flags)
             return eng.finalize(T, K, intensity, fetch)
 
     # ------------------------------------------------------------------ the seam
@@ -370,10 +388,13 @@ class SEDCalculator:
             logger.info("Chirality calculation selected, forcing coherent summation mode.")
             summation_mode = 'coherent'
         k_mags, k_vecs = self.get_k_path(direction, bz_coverage, n_k, lat_param=lat_param)
-        sed = self.calculate(k_mags, k_vecs, basis_atom_indices=basis_atom_indices,
-                             basis_atom_types=basis_atom_types, summation_mode=summation_mode,
-                             k_chunk_size=k_chunk_size)
-        return self._finish(sed, chiral, chiral_axis)
+        # the phase is computed from the result still on the device: no other calculation on this
+        # engine (another thread, another calculator attached to it) may come in between
+        with self.engine.lock:
+            sed = self.calculate(k_mags, k_vecs, basis_atom_indices=basis_atom_indices,
+                                 basis_atom_types=basis_atom_types, summation_mode=summation_mode,
+                                 k_chunk_size=k_chunk_size)
+            return self._finish(sed, chiral, chiral_axis)
 
     def calculate_chiral_sed(self, direction, bz_coverage: float = 1.0, n_k: int = 100,
                              chiral_axis: str = 'z', **kwargs) -> SED:
@@ -393,10 +414,11 @@ class SEDCalculator:
             summation_mode = 'coherent'
         k_mags, k_vecs, shape = self.get_k_grid(plane, (k_ranges[0], k_ranges[1]),
                                                 (k_ranges[2], k_ranges[3]), n_kx, n_ky, k_fixed)
-        sed = self.calculate(k_mags, k_vecs, basis_atom_indices=basis_atom_indices,
-                             basis_atom_types=basis_atom_types, summation_mode=summation_mode,
-                             k_grid_shape=shape, k_chunk_size=k_chunk_size)
-        return self._finish(sed, chiral, chiral_axis)
+        with self.engine.lock:
+            sed = self.calculate(k_mags, k_vecs, basis_atom_indices=basis_atom_indices,
+                                 basis_atom_types=basis_atom_types, summation_mode=summation_mode,
+                                 k_grid_shape=shape, k_chunk_size=k_chunk_size)
+            return self._finish(sed, chiral, chiral_axis)
 
     # ------------------------------------------------------------------ iSED
     def _ised_groups(self, basis_atom_idx_ised, basis_atom_types_ised) -> List[np.ndarray]:
@@ -426,6 +448,23 @@ class SEDCalculator:
         else:
             groups.append(np.arange(n_atoms))
         return groups
+
+    def _single_bin(self, k_vector: np.ndarray, members: np.ndarray, i_w: int, mean_pos_all: np.ndarray) -> np.ndarray:
+        """S[i_w, k, :] (3 complex64) of one k-vector and one atom group: what `calculate(...).sed[i_w, i_k]`
+        would hold (reference :58-84 for one k, one frequency)."""
+        members = np.asarray(members)
+        if np.any(members >= self.traj.n_atoms) or np.any(members < 0):
+            raise ValueError("Atom indices in basis out of bounds.")
+        if self._shard is not None and self._shard.nranks > 1:     # sharded engines hold partial data
+            sed = self.calculate(np.zeros(1, np.float32), np.asarray(k_vector, np.float32)[None, :],
+                                 basis_atom_indices=members)
+            return sed.sed[i_w, 0, :]
+        slot, data, flags = self._data_slot()
+        eng = self.engine
+        with eng.lock:
+            eng.ensure_resident(slot, data)
+            group = self._device_groups([members])
+            return eng.single_bin(slot, mean_pos_all, k_vector, None if group is None else group[0], i_w, flags)
 
     def ised(self, k_dir_spec, k_target: float, w_target: float, char_len_k_path: float,
              nk_on_path: int = 100, bz_cov_ised: float = 1.0,
@@ -459,13 +498,16 @@ class SEDCalculator:
         auto = isinstance(rescale_factor, str) and rescale_factor.lower() == "auto"
         peak, spread_sum, spread_atoms = 0.0, 0.0, 0
 
+        # Of each group's path spectrum the reference consumes ONE bin, sed[i_w, i_k, :] (:483,
+        # :494-499).  Only that bin is computed: one k-vector projected over the trajectory and one
+        # DFT dot (psa_sed_single_bin) instead of nk_on_path projections and 3 nk_on_path FFTs.
+        freqs = np.fft.fftfreq(self.traj.n_frames, d=self.dt_ps)
+        i_w = int(np.argmin(np.abs(freqs - w_target)))
         for members in groups:
-            sed = self.calculate(k_points_mags=k_mags, k_vectors_3d=k_vecs, basis_atom_indices=members,
-                                 k_grid_shape=None, summation_mode='coherent')
-            i_w = int(np.argmin(np.abs(sed.freqs - w_target)))
+            amplitude = self._single_bin(k_vecs[i_k], members, i_w, mean_pos)
             carrier = np.exp(1j * tau[:, None] - 1j * k_used * along_k[members][None, :])
             for axis in range(3):
-                motion[:, members, axis] += np.real(sed.sed[i_w, i_k, axis] * carrier)
+                motion[:, members, axis] += np.real(amplitude[axis] * carrier)
             if auto:
                 peak = max(peak, float(np.amax(np.abs(motion[:, members, :3]))))
                 thermal = self.traj.positions[:, members, :] - mean_pos[None, members, :]

@@ -21,6 +21,14 @@
 // written with row stride q_stride so that a launch may cover a frame sub-range of a longer slab.
 #include "k1_f16.h"
 
+// Schedule experiments (tools/k1_experiments.sh builds side libraries with -DPSA_K1P_X=bits):
+//   1: the second row half (waves 4-7, the SIMD partners of 0-3) issues its DMA half a stage later
+//   2: s_setprio 1 for waves 4-7      4: DMA pieces spread over the row-tile regions
+//   8: B-fragment reads spread over the regions   16: no sched_barrier between the regions
+#ifndef PSA_K1P_X
+#define PSA_K1P_X 19        // product build: stagger + priority + free scheduling (14.9 ms vs 16.0 at 0, configuration 3)
+#endif
+
 namespace psa {
 
 template <int MT16_, int RING_>
@@ -76,15 +84,21 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
     const int            pw = C::P_PIECES >= 8 ? w * C::P_DMA : (w & 3);
     const unsigned char* pp = reinterpret_cast<const unsigned char*>(Pb) + (size_t)mb * n_stage * C::P_STAGE_BYTES +
                               1024 * pw + 16 * lane;
-    auto dma_stage = [&](int st, int slot) {
+    // piece i of this wavefront's BATCH for stage st (clamped) -> slot: P' pieces first, then V
+    auto dma_piece = [&](int i, int st, int slot) {
         const int      sc = st < last ? st : last;
         const unsigned dst = lds0 + slot * C::STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < C::P_DMA; ++i)
+        if (i < C::P_DMA) {
             lds_dma16(pp + (size_t)sc * C::P_STAGE_BYTES + 1024 * i, dst + 1024 * (pw + i));
-        const unsigned vdst = dst + C::P_STAGE_BYTES + wf * C::V_GROUP_BYTES + 1024 * (wh * C::V_DMA);
+        } else {
+            const int      j = i - C::P_DMA;
+            const unsigned vdst = dst + C::P_STAGE_BYTES + wf * C::V_GROUP_BYTES + 1024 * (wh * C::V_DMA);
+            lds_dma16(vp + (size_t)sc * C::V_GROUP_BYTES + 1024 * j, vdst + 1024 * j);
+        }
+    };
+    auto dma_stage = [&](int st, int slot) {
 #pragma unroll
-        for (int j = 0; j < C::V_DMA; ++j) lds_dma16(vp + (size_t)sc * C::V_GROUP_BYTES + 1024 * j, vdst + 1024 * j);
+        for (int i = 0; i < C::BATCH; ++i) dma_piece(i, st, slot);
     };
 
     // ---- LDS read addresses: both images use the 64-byte rows / swizzled 16-byte slots of k1_f16.h
@@ -100,13 +114,12 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
         for (int p = 0; p < NP; ++p)
             a[p][mt] = *reinterpret_cast<lds_cv8*>((const lds_u8*)(size_t)(base + (p * C::M_BLK + mt * 16) * 64));
     };
+    auto read_b1 = [&](int par, int slot, int i) {
+        bs[par][i >> 1][i & 1] = *reinterpret_cast<lds_cv8*>((const lds_u8*)(size_t)(v_lane + slot * C::STAGE_BYTES + i * 1024));
+    };
     auto read_b = [&](int par, int slot) {
-        const unsigned base = v_lane + slot * C::STAGE_BYTES;
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int p = 0; p < NP; ++p)
-                bs[par][c][p] = *reinterpret_cast<lds_cv8*>((const lds_u8*)(size_t)(base + (c * NP + p) * 1024));
+        for (int i = 0; i < 3 * NP; ++i) read_b1(par, slot, i);
     };
 #pragma unroll
     for (int mt = 0; mt < MT16; ++mt)
@@ -116,6 +129,9 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
             lo[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
+    if constexpr ((PSA_K1P_X & 2) != 0) {
+        if (wh == 1) __builtin_amdgcn_s_setprio(1);
+    }
     // ---- prologue: stages 0 .. RING-1 in flight; stage 0 into registers --------------------------
 #pragma unroll
     for (int k = 0; k < C::RING; ++k) dma_stage(k, k);
@@ -142,15 +158,30 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
         constexpr int  par = decltype(par_c)::value;
         constexpr bool restart = decltype(restart_c)::value;
         const int      slot1 = slot == C::RING - 1 ? 0 : slot + 1;
-        dma_stage(s + C::RING, slot);
-        read_b(par ^ 1, slot1);
-        __builtin_amdgcn_sched_barrier(0);
+        constexpr bool STAGGER = (PSA_K1P_X & 1) != 0, SPREAD_DMA = (PSA_K1P_X & 4) != 0,
+                       SPREAD_B = (PSA_K1P_X & 8) != 0, FREE = (PSA_K1P_X & 16) != 0;
+        if constexpr (!SPREAD_DMA) {
+            if (!STAGGER || wh == 0) dma_stage(s + C::RING, slot);
+        }
+        if constexpr (!SPREAD_B) read_b(par ^ 1, slot1);
+        if constexpr (!FREE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < MT16; ++mt) {
+            if constexpr (SPREAD_B) {
+#pragma unroll
+                for (int i = mt * 6 / MT16; i < (mt + 1) * 6 / MT16; ++i) read_b1(par ^ 1, slot1, i);
+            }
+            if constexpr (SPREAD_DMA) {
+#pragma unroll
+                for (int i = mt * C::BATCH / MT16; i < (mt + 1) * C::BATCH / MT16; ++i) dma_piece(i, s + C::RING, slot);
+            }
             mfma_tile(mt, par, restart);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!FREE) __builtin_amdgcn_sched_barrier(0);
             read_a_tile(mt, slot1);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (STAGGER && !SPREAD_DMA) {
+                if (mt == (MT16 - 1) / 2 && wh == 1) dma_stage(s + C::RING, slot);
+            }
+            if constexpr (!FREE) __builtin_amdgcn_sched_barrier(0);
         }
         // own blocks of stage s+2 landed (younger batches stay in flight), own LDS reads returned
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((C::RING - 2) * C::BATCH) : "memory");

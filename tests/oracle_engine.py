@@ -22,6 +22,29 @@ class OracleEngine:
     # residency
     def ensure_resident(self, slot, array):
         self.slots[slot] = np.asarray(array, np.float32)
+        self.uploads = getattr(self, "uploads", 0) + 1
+        self._held = getattr(self, "_held", {})
+        self._held[slot] = array
+
+    def is_resident(self, slot, array):
+        return getattr(self, "_held", {}).get(slot) is array
+
+    def invalidate(self, slot=None):
+        self._held = {}
+
+    def project_upload(self, slot, array, mean_pos_all, k_vectors, groups=None, flags=0):
+        self.ensure_resident(slot, array)
+        self.project(slot, mean_pos_all, k_vectors, groups, flags)
+        self.calls[-1]["streamed"] = True
+
+    def single_bin(self, slot, mean_pos_all, k_vector, idx, i_w, flags=0):
+        data = self.slots[slot]
+        g = np.arange(data.shape[1]) if idx is None else np.asarray(idx)
+        s = O.sed_for_group(data, data, np.asarray(k_vector, np.float32).reshape(1, 3), g,
+                            np.asarray(mean_pos_all, np.float32),
+                            use_displacements=bool(flags & _hip.F_DISPLACEMENTS))
+        self.calls.append(dict(single_bin=True, i_w=i_w, n=len(g)))
+        return s[i_w, 0, :]
 
     def shape(self, slot):
         return self.slots[slot].shape[:2]
@@ -99,3 +122,39 @@ class OracleEngine:
 
     def close(self):
         pass
+
+    # frame sharding: the slot holds this rank's frames only
+    def fs_project(self, slot, mean_pos_all, k_vectors, idx, flags, T_total, k_offset, k_count):
+        data = self.slots[slot]
+        T_local, N = data.shape[:2]
+        g = np.arange(N) if idx is None else np.asarray(idx)
+        mean = np.asarray(mean_pos_all, np.float32)
+        intensity = bool(flags & _hip.F_INTENSITY)
+        K = len(k_vectors)
+        if self._slab is None or self._meta != (T_total, K, intensity):
+            self._slab = np.zeros((K, T_total) if intensity else (K, 3, T_total), np.float32 if intensity else np.complex64)
+            self._meta = (T_total, K, intensity)
+        sel = data[:, g, :] - mean[g][None] if flags & _hip.F_DISPLACEMENTS else data[:, g, :]
+        q = O.project_group(sel, O.phase_table(np.asarray(k_vectors, np.float32), mean[g]))    # (T_local, K, 3)
+        self._fs = dict(q=np.ascontiguousarray(q.transpose(1, 2, 0)), T=T_total, k0=k_offset, nk=k_count,
+                        intensity=intensity, rows=np.zeros((k_count, 3, T_total), np.complex64))
+        self.calls.append(dict(fs=True, K_total=K, k_offset=k_offset, K=k_count, T_local=T_local))
+
+    def fs_read(self, k0, nk, T_local):
+        return self._fs["q"][k0:k0 + nk].copy()
+
+    def fs_write(self, t0, block):
+        self._fs["rows"][:, :, t0:t0 + block.shape[2]] = block
+
+    def fs_exchange(self, t_off, t_cnt, k_off, k_cnt):
+        raise AssertionError("the test double has no RCCL: the exchange must go through the host transport")
+
+    def fs_finish(self, first_group):
+        f = self._fs
+        spec = (np.fft.fft(f["rows"], axis=2) / f["T"]).astype(np.complex64)       # sed_calculator.py:83-84
+        rows = slice(f["k0"], f["k0"] + f["nk"])
+        if f["intensity"]:
+            inten = np.sum(np.abs(spec) ** 2, axis=1).astype(np.float32)
+            self._slab[rows] = inten if first_group else self._slab[rows] + inten
+        else:
+            self._slab[rows] = spec

@@ -62,8 +62,8 @@ def test_root_heavy_counts_with_free_links_is_the_even_split():
     assert list(cnt) == [64, 64, 64, 64]
 
 
-def _sharded_worker(rank, world, port, backend, gather, results, no_rccl=False, balance=None):
-    """One rank of a 2-process k-sharded `calculate` (oracle-backed engine)."""
+def _sharded_worker(rank, world, port, backend, gather, results, no_rccl=False, balance=None, mode="k"):
+    """One rank of a 2-process sharded `calculate` (oracle-backed engine)."""
     import numpy as np
     import conftest
     from oracle_engine import OracleEngine
@@ -94,11 +94,18 @@ def _sharded_worker(rank, world, port, backend, gather, results, no_rccl=False, 
                 for r, rows in enumerate(parts):
                     self._slab[int(k_offsets[r]):int(k_offsets[r] + k_counts[r])] = rows
 
+        def fs_exchange(self, t_off, t_cnt, k_off, k_cnt):       # the "RCCL" all-to-all of the double
+            assert not no_rccl
+            parts = ex.allgather(self._fs["q"])
+            lo, n = int(k_off[self.rank]), int(k_cnt[self.rank])
+            for r, q in enumerate(parts):
+                self.fs_write(int(t_off[r]), np.asarray(q)[lo:lo + n])
+
     with np.load(conftest.GOLDEN / "traj_a.npz") as z:
         d = {k: z[k] for k in z.files}
     d["dt_ps"], d["cells"] = float(d["dt_ps"]), tuple(int(v) for v in d["cells"])
     eng = ExchangeEngine(rank=rank)
-    group = D.KShardGroup(eng, ex, gather=gather, root=0, balance=balance)
+    group = D.KShardGroup(eng, ex, gather=gather, root=0, balance=balance, mode=mode)
     calc = conftest.make_calculator(d).attach(shard_group=group)
     mags, vecs = calc.get_k_path([1, 1, 0], 2.0, 7)               # 7 k-points over 2 ranks: 4 + 3
     out = {}
@@ -106,7 +113,9 @@ def _sharded_worker(rank, world, port, backend, gather, results, no_rccl=False, 
         sed = calc.calculate(mags, vecs, **kw)
         out[name] = None if sed.sed is None else np.array(sed.sed)
         out[name + "_range"] = (eng.calls[-1]["k_offset"], eng.calls[-1]["K"], eng.calls[-1]["K_total"])
+        out[name + "_frames"] = eng.slots[0].shape[0]
     out["transport"] = group.transport
+    out["mode"] = group.last_mode
     ex.barrier()
     results[rank] = out
     group.close()
@@ -115,17 +124,20 @@ def _sharded_worker(rank, world, port, backend, gather, results, no_rccl=False, 
         td.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend, gather, no_rccl, balance", [
-    ("gloo", "all", False, None), ("gloo", "root", False, None), ("tcp", "all", False, None),
-    ("gloo", "root", True, None), ("gloo", "root", False, MODEL), ("tcp", "all", False, MODEL)])
-def test_two_rank_sharded_calculate_equals_unsharded(backend, gather, no_rccl, balance):
+@pytest.mark.parametrize("backend, gather, no_rccl, balance, mode", [
+    ("gloo", "all", False, None, "k"), ("gloo", "root", False, None, "k"), ("tcp", "all", False, None, "k"),
+    ("gloo", "root", True, None, "k"), ("gloo", "root", False, MODEL, "k"), ("tcp", "all", False, MODEL, "k"),
+    ("gloo", "all", False, None, "frames"), ("tcp", "root", False, None, "frames"),
+    ("tcp", "all", True, None, "frames"), ("gloo", "root", False, MODEL, "auto")])
+def test_two_rank_sharded_calculate_equals_unsharded(backend, gather, no_rccl, balance, mode):
     import conftest
     from oracle import psa_oracle as O
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         results = mgr.dict()
-        procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, backend, gather, results, no_rccl, balance))
+        procs = [ctx.Process(target=_sharded_worker,
+                             args=(r, world, port, backend, gather, results, no_rccl, balance, mode))
                  for r in range(world)]
         for p in procs:
             p.start()
@@ -141,10 +153,14 @@ def test_two_rank_sharded_calculate_equals_unsharded(backend, gather, no_rccl, b
     ref_c, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], float(d["dt_ps"]), vecs)
     ref_i, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], float(d["dt_ps"]), vecs,
                               basis_atom_types=[1, 2], summation_mode="incoherent")
-    if balance and gather == "root":                      # 7 rows, sending costs 4 per row: the root takes 6
+    frames = mode in ("frames", "auto")                   # 7 k-vectors over 2 ranks: "auto" picks frames
+    assert res[0]["mode"] == res[1]["mode"] == ("frames" if frames else "k")
+    if balance and gather == "root" and not frames:       # 7 rows, sending costs 4 per row: the root takes 6
         assert res[0]["coh_range"] == (0, 6, 7) and res[1]["coh_range"] == (6, 1, 7)
-    else:                                                 # (gather="all" ignores the model)
+    else:                                                 # (gather="all" and frame sharding ignore the model)
         assert res[0]["coh_range"] == (0, 4, 7) and res[1]["coh_range"] == (4, 3, 7)
+    # frame sharding keeps half of the 128 frames on each rank, k sharding all of them
+    assert res[0]["coh_frames"] == res[1]["inc_frames"] == (64 if frames else 128)
     assert res[0]["transport"] == res[1]["transport"] == ("host" if no_rccl else "rccl")
     for rank in range(world):
         if gather == "root" and rank != 0:

@@ -1,6 +1,8 @@
 """CPU tests of the product's host side (no GPU): the mirrored reference classes, the k
 generators and constructor against the golden vectors, group resolution against the
 oracle, and `calculate`'s orchestration with the oracle-backed test double."""
+import os
+
 import numpy as np
 import pytest
 
@@ -360,3 +362,88 @@ def test_displacement_mode_takes_the_mean_from_the_device(trajs):
     assert 1 in eng.slots                                             # positions were made resident
     np.testing.assert_array_equal(mean, O.mean_positions(d["positions"]))
     assert calc._mean_positions() is mean
+
+
+def test_first_calculate_streams_the_upload_then_reuses_the_resident_array(trajs):
+    """Host logic of residency: an array the engine does not hold goes through `project_upload`
+    (upload and projection overlapped), later calls through `project`; `invalidate()` forgets."""
+    from oracle_engine import OracleEngine
+    eng = OracleEngine()
+    calc = make_calculator(trajs["a"]).attach(engine=eng)
+    mags, vecs = calc.get_k_path("100", 1.0, 8)
+    first = calc.calculate(mags, vecs)
+    assert eng.calls[-1].get("streamed") and eng.uploads == 1
+    second = calc.calculate(mags, vecs, basis_atom_types=[1, 2], summation_mode="incoherent")
+    assert not eng.calls[-1].get("streamed") and eng.uploads == 1
+    calc.invalidate()
+    assert calc._mean_cache is None
+    third = calc.calculate(mags, vecs)
+    assert eng.calls[-1].get("streamed") and eng.uploads == 2
+    np.testing.assert_array_equal(first.sed, third.sed)
+    assert second.sed.shape == (128, 8)
+
+
+def test_ised_computes_one_bin_per_group(trajs, tmp_path):
+    """iSED asks the engine for the single (k, omega) bin of each group, not for path spectra."""
+    from golden import cases as C
+    from oracle_engine import OracleEngine
+    eng = OracleEngine()
+    calc = make_calculator(trajs["a"]).attach(engine=eng)
+    name, _, kw = C.ISED_CASES[1]                                   # three type groups
+    calc.ised(dump_filepath=str(tmp_path / "x.dump"), **kw)
+    bins = [c for c in eng.calls if c.get("single_bin")]
+    assert len(bins) == 3 and len({c["i_w"] for c in bins}) == 1
+    assert not any("K" in c for c in eng.calls)                     # no full projection at all
+
+
+def test_rendezvous_wire_format_round_trips_and_rejects_garbage():
+    from psa_amd import dist
+    obj = [None, True, 3, 2.5, "text", b"\x00\x01raw", np.arange(12, dtype=np.complex64).reshape(3, 4),
+           [np.float32(1.5), np.int64(7), (1, 2)], np.zeros((0, 3), np.float32)]
+    back = dist._decode(dist._encode(obj))
+    assert back[:5] == [None, True, 3, 2.5, "text"] and back[5] == b"\x00\x01raw"
+    np.testing.assert_array_equal(back[6], obj[6])
+    assert back[6].dtype == np.complex64 and back[7] == [1.5, 7, [1, 2]] and back[8].shape == (0, 3)
+    with pytest.raises(TypeError):
+        dist._encode({"a": 1})                                      # only plain data crosses
+    with pytest.raises(TypeError):
+        dist._encode(np.array([object()]))
+    import pickle
+    with pytest.raises(Exception):
+        dist._decode(pickle.dumps([1, 2, 3]))                       # never unpickled
+    blob = dist._encode(np.arange(10))
+    with pytest.raises(ConnectionError):
+        dist._decode(blob[:-3])                                     # truncated payload
+
+
+def test_tcp_rendezvous_ignores_strangers_and_duplicates():
+    """Rank 0 drops connections that announce rank 0, a rank out of range, or one already taken."""
+    import socket
+    import struct
+    import threading
+    from psa_amd import dist
+    port = 29000 + (os.getpid() % 2000)
+    box = {}
+    t = threading.Thread(target=lambda: box.setdefault("ex", dist.TcpExchange(0, 2, "127.0.0.1", port, timeout_s=20)))
+    t.start()
+    for bad in (0, 7):
+        for _ in range(200):
+            try:
+                s = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+                break
+            except OSError:
+                import time
+                time.sleep(0.02)
+        s.sendall(struct.pack("<I", bad))
+        s.close()
+    peer = dist.TcpExchange(1, 2, "127.0.0.1", port, timeout_s=20)
+    t.join(20)
+    assert "ex" in box
+    res = {}
+    t2 = threading.Thread(target=lambda: res.setdefault("r0", box["ex"].allgather("zero")))
+    t2.start()
+    assert peer.allgather(np.arange(3)) [0] == "zero"
+    t2.join(20)
+    np.testing.assert_array_equal(res["r0"][1], np.arange(3))
+    peer.close()
+    box["ex"].close()
