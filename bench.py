@@ -3,72 +3,144 @@
 SED hot-path benchmark (contract: see the task's bench.py section).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--summation coherent]
+                    [--shard auto|k|frames]
 
-One "step" = one pass of the hot path over one synthetic trajectory already resident in
-HBM: phase table -> fp32-MFMA k-projection -> batched rocFFT over time -> scale/|.|^2
-epilogue -> (N>1: RCCL gather of the k-shards to rank 0) -> transpose to the reference's
-(T,K,3) layout + SED.intensity, result left on the device.  Default workload is the
-configuration BASELINE.json's target is quoted on (C3: 32768 atoms x 65536 steps x 256
-k-points, [110] path, basis types [1,2]); it fits one MI355X.  With N GPUs the 256
-k-points are sharded over the ranks (total work fixed -> "strong" scaling), each rank holding
-its own copy of the trajectory.
+One "step" = one pass of the hot path over one synthetic trajectory already resident in HBM:
+phase table -> k-projection (split-precision f16 MFMA from the group's cached split planes,
+fp32-equivalent) -> batched rocFFT over time -> scale / |.|^2 epilogue -> (N > 1: exchange, see
+below) -> transpose to the reference's (T,K,3) layout + SED.intensity, result left on the device.
+Default workload is the configuration BASELINE.json's target is quoted on (C3: 32768 atoms x 65536
+steps x 256 k-points, [110] path, basis types [1,2]); it fits one MI355X.  The same JSON line
+carries `end_to_end` (the public `SEDCalculator.calculate` on the resident trajectory, result as a
+host ndarray) and `variants` (the other summation mode: the two basis types as separate groups).
 
-Launch for N>1 (one process per GPU):
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
-torch.distributed (gloo) is used only as the host rendezvous: unique-id broadcast, barriers,
-max-over-ranks of the wall time.  The data path is libpsa_hip.so + RCCL.
+N > 1: one process per GPU.  `python bench.py --gpus N` starts the N ranks itself (children of
+this process, before anything touches HIP); under a launcher that already exported WORLD_SIZE
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) it is one of the ranks.
+Host rendezvous (RCCL unique id, barriers, max of the wall times) is a small TCP exchange on
+MASTER_ADDR:MASTER_PORT+17; the data path is libpsa_hip.so + RCCL over xGMI.  Sharding
+(psa_amd/dist.py): "k" = every rank holds the whole trajectory and projects its block of
+k-points, gather to rank 0; "frames" = every rank holds 1/N of the frames, projects all k-points
+on them, all-to-all before the FFT, gather to rank 0; "auto" = frames when a rank's k-block would be
+<= 64 k-points.  Total work is fixed as N grows -> "scaling": "strong".
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
-
-import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL needs it on this pool
 
-from psa_amd import _hip, dist, synth                      # noqa: E402
-from psa_amd.core.sed_calculator import SEDCalculator      # noqa: E402
-from psa_amd.core.trajectory import Trajectory             # noqa: E402
+
+def _one_socket_cores():
+    """Logical CPUs of ONE socket among those this process may run on, one per physical core:
+    the CPU baseline is a 1-socket NumPy run (BASELINE.json north_star)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    by_socket = {}
+    for cpu in allowed:
+        base = Path(f"/sys/devices/system/cpu/cpu{cpu}/topology")
+        try:
+            pkg = int((base / "physical_package_id").read_text())
+            core = int((base / "core_id").read_text())
+        except (OSError, ValueError):
+            pkg, core = 0, cpu
+        by_socket.setdefault(pkg, {}).setdefault(core, cpu)
+    first = by_socket[min(by_socket)]
+    return sorted(first.values()), len(by_socket)
+
+
+# BLAS threads = physical cores of one socket; must be in the environment before NumPy loads
+_SOCKET_CPUS, _N_SOCKETS = _one_socket_cores()
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ[_v] = str(len(_SOCKET_CPUS))
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md:41-42 (dense, v_mfma_f32_32x32x2_f32)
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # ibid. :43 (dense bf16 MFMA)
-SPLIT_MFMA_FLOP_PER_UNIT = {"auto": 36, "bf16x3": 72}   # 16-bit products issued per fp32 product: 3 (2xf16) / 6 (3xbf16)
+PEAK_16BIT_MFMA_TFLOPS = 2500.0   # ibid. :43 (dense f16 / bf16 MFMA)
 PEAK_HBM_GBS = 8000.0             # ibid. :36 (spec; 6.29 TB/s measured copy)
 FLOP_PER_UNIT = 12                # 3 components x (re, im) x FMA per (k, t, atom)  (SURVEY.md 8d)
-# k-split model for N > 1 (measured on one MI355X, DESIGN.md section 3; the link rate is an assumption)
-K1_UNITS_PER_S = 3.4e13           # slope of the f16 projection kernel's time over the k-count
-HBM_BOUND_K1_BPS = 5.3e12         # trajectory bytes per second of its HBM-bound small-K variant
+# k-split model for N > 1, mode "k" (one-GPU measurements, DESIGN.md section 3; the link rate is an assumption)
+K1_UNITS_PER_S = 4.3e13           # slope of the planes kernel's time over the k-count
+HBM_BOUND_K1_BPS = 6.2e12         # trajectory bytes per second of its HBM-bound small-K variant
 XGMI_LINK_BPS = 64e9              # one direction of one xGMI link
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--summation", default="coherent", choices=["coherent", "incoherent"])
+    ap.add_argument("--shard", default="auto", choices=["auto", "k", "frames"],
+                    help="N > 1: how the calculation is split over the ranks (psa_amd/dist.py)")
     ap.add_argument("--k-points", type=int, default=0,
                     help="override the config's k-point count (diagnostics, e.g. 32 = one rank's shard of C3 on 8 GPUs)")
-    ap.add_argument("--k1", default="auto", choices=["auto", "bf16x3", "mfma32"],
-                    help="projection kernel: auto = split-precision 2xf16 MFMA (product default), "
-                         "bf16x3 = split-precision 3xbf16 MFMA, mfma32 = exact-fp32 MFMA")
+    ap.add_argument("--k1", default="auto", choices=["auto", "onthefly", "bf16x3", "mfma32"],
+                    help="projection kernel: auto = 2xf16 split-precision MFMA from cached split planes (product "
+                         "default), onthefly = the same arithmetic splitting in the kernel (no plane cache), "
+                         "bf16x3 = 3xbf16 split-precision MFMA, mfma32 = exact-fp32 MFMA")
     ap.add_argument("--even-split", action="store_true",
-                    help="N > 1: give every rank the same number of k-points instead of the root-heavy split")
-    ap.add_argument("--check", action="store_true",
-                    help="after timing, rank 0 recomputes every k-point on its own GPU and compares the "
-                         "gathered result with it (multi-rank plumbing check)")
+                    help="N > 1, mode k: give every rank the same number of k-points instead of the root-heavy split")
+    ap.add_argument("--no-check", action="store_true",
+                    help="N > 1: skip the comparison of the gathered result with a one-GPU recomputation on rank 0")
+    ap.add_argument("--check", action="store_true", help="N = 1: no effect (kept for old command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip end_to_end and variants (kernel experiments)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU-baseline sample (0 = auto)")
-    return ap.parse_args()
+    ap.add_argument("--stub-engine", action="store_true",
+                    help="TEST ONLY: run the orchestration (spawn, rendezvous, sharding, host exchange, JSON) with an "
+                         "engine that computes nothing; the line is marked and carries no measurement")
+    return ap.parse_args(argv)
 
 
+# --------------------------------------------------------------------------- self-launch
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """Start the n ranks as children of this process (which has not loaded libpsa_hip, HIP or
+    NumPy-side GPU state), relay rank 0's JSON line, return non-zero if any rank fails."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PSA_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    deadline = time.time() + 600
+    codes = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes.append(-9)
+    if any(codes):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
+        return 1
+    lines = [ln for ln in out.decode().splitlines() if ln.strip()]
+    if len(lines) != 1:
+        sys.stderr.write(f"bench.py: rank 0 printed {len(lines)} lines instead of one\n")
+        return 1
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+# --------------------------------------------------------------------------- helpers
 def k_request(calc, req):
     if req["kind"] == "path":
         mags, vecs = calc.get_k_path(req["direction"], req["bz_coverage"], req["n_k"])
@@ -77,61 +149,127 @@ def k_request(calc, req):
     return calc.get_k_grid(req["plane"], (r[0], r[1]), (r[2], r[3]), req["n_kx"], req["n_ky"], 0.0)
 
 
-def cpu_baseline(spec, tables, r0, types, vecs, kw, n_frames):
-    """The oracle (NumPy restatement of the reference path, same operations and dtypes) timed
-    on this box's host cores over a bounded sample: the first `n_frames` frames, all atoms,
-    all k-points.  Throughput is per (k, t, atom) unit, so the sample rate is the full-size
-    rate up to the FFT's log factor (< 3 % of the reference's time)."""
-    from oracle import psa_oracle as O
-    vel = np.concatenate([synth.velocities_block(spec, tables, t, min(128, n_frames - t))
-                          for t in range(0, n_frames, 128)])
-    pos = np.broadcast_to(r0, (n_frames,) + r0.shape)     # static lattice: no second big array
-    O.calculate(pos[:8], vel[:8], types, spec.dt_ps, vecs[:2], **kw)       # warm BLAS/threads
-    best = float("inf")
-    for _ in range(2):
-        t0 = time.perf_counter()
-        sed, _, is_complex = O.calculate(pos, vel, types, spec.dt_ps, vecs, **kw)
-        inten = O.intensity(sed) if is_complex else sed
-        best = min(best, time.perf_counter() - t0)
-    n_units = sum_group_atoms(types, kw) * n_frames * len(vecs)
-    # the mean the oracle used: a float32 running sum over frames drifts off r0 itself
-    # (sed_calculator.py:205); the parity leg must feed the GPU the same numbers
-    return n_units / best, best, vel, inten, O.mean_positions(pos)
-
-
 def sum_group_atoms(types, kw):
     """Atoms the projection sums over (incoherent: the sum over groups)."""
+    import numpy as np
     t = kw.get("basis_atom_types")
     if not t:
         return len(types)
     return int(np.isin(types, t).sum())
 
 
+def cpu_model():
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(spec, tables, r0, types, vecs, kw, n_frames, reps=3):
+    """The oracle (NumPy restatement of the reference path, same operations and dtypes) timed on one
+    socket of this box over a bounded sample: the first `n_frames` frames, all atoms, all k-points.
+    Throughput is per (k, t, atom) unit, so the sample rate is the full-size rate up to the FFT's
+    log factor (< 3 % of the reference's time)."""
+    import numpy as np
+    from oracle import psa_oracle as O
+    from psa_amd import synth
+    before = os.sched_getaffinity(0)
+    os.sched_setaffinity(0, set(_SOCKET_CPUS))
+    try:
+        vel = np.concatenate([synth.velocities_block(spec, tables, t, min(128, n_frames - t))
+                              for t in range(0, n_frames, 128)])
+        pos = np.broadcast_to(r0, (n_frames,) + r0.shape)     # static lattice: no second big array
+        O.calculate(pos[:8], vel[:8], types, spec.dt_ps, vecs[:2], **kw)       # warm BLAS/threads
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            sed, _, is_complex = O.calculate(pos, vel, types, spec.dt_ps, vecs, **kw)
+            inten = O.intensity(sed) if is_complex else sed
+            times.append(time.perf_counter() - t0)
+        mean = O.mean_positions(pos)
+    finally:
+        os.sched_setaffinity(0, before)
+    n_units = float(sum_group_atoms(types, kw)) * n_frames * len(vecs)
+    # the mean the oracle used: a float32 running sum over frames drifts off r0 itself
+    # (sed_calculator.py:205); the parity leg must feed the GPU the same numbers
+    return n_units, times, vel, inten, mean
+
+
+class _StubEngine:
+    """TEST ONLY (--stub-engine): the Engine interface with no GPU behind it, so that the
+    multi-process orchestration can run in a container without one.  Computes nothing."""
+
+    def __init__(self, rank=0):
+        import numpy as np
+        self.np, self.rank, self.nranks, self.slot = np, rank, 1, {}
+        self._slab = self._fs = None
+
+    def device_info(self):
+        return {"name": "stub (no GPU)", "compute_units": 0, "hbm_bytes": 0}
+
+    def set_k1(self, s): pass
+    def set_option(self, o, v): pass
+    def alloc(self, slot, T, N): self.slot[slot] = (T, N)
+    def fill_synthetic(self, *a, **k): pass
+    def shape(self, slot): return self.slot[slot]
+    def synchronize(self): pass
+    def timings(self): return dict.fromkeys(("h2d", "phase", "project", "fft", "epilogue", "gather", "transpose", "d2h"), 0.0)
+    def k1_stats(self): return 0, 0.0
+    def oneoff_stats(self): return dict.fromkeys(("rocfft_plan", "absmax", "split_planes", "upload"), 0.0)
+    def new_unique_id(self): return b"\0" * 128
+    def comm_destroy(self): self.nranks = 1
+    def close(self): pass
+
+    def comm_init(self, uid, rank, nranks):
+        from psa_amd import _hip
+        self.rank, self.nranks = rank, nranks
+        raise _hip.PsaHipError("stub engine: no RCCL")          # -> the host transport is exercised
+
+    def _ensure(self, T, K, intensity):
+        shape = (K, T) if intensity else (K, 3, T)
+        if self._slab is None or self._slab.shape != shape:
+            self._slab = self.np.zeros(shape, self.np.float32 if intensity else self.np.complex64)
+
+    def project(self, slot, mean, kv, groups=None, flags=0, K_total=None, k_offset=0):
+        T = self.slot[slot][0]
+        self._ensure(T, len(kv) if K_total is None else K_total, bool(flags & 2))
+        self._slab[k_offset:k_offset + len(kv)] = self.rank + 1
+
+    def fs_project(self, slot, mean, kv, idx, flags, T_total, k_offset, k_count):
+        self._ensure(T_total, len(kv), bool(flags & 2))
+        self._fs = (self.np.full((len(kv), 3, self.slot[slot][0]), self.rank + 1, self.np.complex64), k_offset, k_count, T_total)
+
+    def fs_read(self, k0, nk, T_local): return self._fs[0][k0:k0 + nk]
+    def fs_write(self, t0, block): pass
+    def fs_finish(self, first): self._slab[self._fs[1]:self._fs[1] + self._fs[2]] = self.rank + 1
+    def slab_read(self, row0, nrows, T, intensity): return self._slab[row0:row0 + nrows]
+    def slab_write(self, row0, rows): self._slab[row0:row0 + len(rows)] = rows
+    def finalize(self, T, K, intensity, fetch=True): return self._slab if fetch else None
+
+
+# --------------------------------------------------------------------------- one rank
 def main():
     args = parse_args()
-    # The contract is ONE JSON line on stdout.  Gloo and RCCL print banners to fd 1, so the real
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))          # before libpsa_hip / HIP are touched
+    import numpy as np
+    from psa_amd import _hip, dist, synth
+    from psa_amd.core.sed_calculator import SEDCalculator
+    from psa_amd.core.trajectory import Trajectory
+
+    # The contract is ONE JSON line on stdout.  RCCL prints banners to fd 1, so the real
     # stdout is set aside and everything else is routed to stderr.
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    # libpsa_hip (and with it /opt/rocm's HIP runtime, rocFFT, RCCL) is loaded BEFORE torch so that
-    # single- and multi-process runs execute the very same libraries; torch is only used for its
-    # gloo rendezvous below.
-    _hip.load_library()
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with "
-                     f"python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py")
-        args.gpus = world
-
-    exchange = dist.Exchange()
-    if world > 1:
-        import torch.distributed as td
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("gloo")
-        exchange = dist.TorchExchange()
+    args.gpus = world
+    exchange = dist.TcpExchange.from_env(timeout_s=600.0) if world > 1 else dist.Exchange()
 
     spec, req = synth.baseline_spec(args.config)
     if args.k_points and req["kind"] == "path":
@@ -140,15 +278,23 @@ def main():
     tables = synth.mode_tables(spec, r0)
     T, N = spec.n_frames, spec.n_atoms
 
-    engine = _hip.Engine(local_rank % max(1, _hip.device_count()))
+    if args.stub_engine:
+        engine = _StubEngine(rank)
+    else:
+        _hip.load_library()
+        engine = _hip.Engine(local_rank % max(1, _hip.device_count()))
     info = engine.device_info()
-    engine.set_k1({"auto": _hip.K1_AUTO, "bf16x3": _hip.K1_SPLIT_BF16, "mfma32": _hip.K1_MFMA32}[args.k1])
-    synth.fill_device(engine, _hip.SLOT_VELOCITIES, spec, tables)     # V generated in HBM
-    group = dist.KShardGroup(engine, exchange, gather="root", root=0)
+    engine.set_k1({"auto": _hip.K1_AUTO, "onthefly": _hip.K1_AUTO, "bf16x3": _hip.K1_SPLIT_BF16,
+                   "mfma32": _hip.K1_MFMA32}[args.k1])
+    if args.k1 == "onthefly":
+        engine.set_option(_hip.OPT_PLANES, 0)
+    group = dist.KShardGroup(engine, exchange, gather="root", root=0, mode=args.shard)
 
-    # host objects only for the k generators / group resolution (no big arrays on the host)
-    stub = np.zeros((1, N, 3), np.float32)
-    traj = Trajectory(stub, stub, types, np.zeros(1, np.float32), box, np.diag(box).copy(),
+    # host objects only for the k generators / group resolution (no big arrays on the host):
+    # zero-stride stand-ins of the trajectory's shape
+    stand_in = np.broadcast_to(np.float32(0), (T, N, 3))
+    pos_stand_in = np.broadcast_to(r0, (T, N, 3))
+    traj = Trajectory(pos_stand_in, stand_in, types, np.broadcast_to(np.float32(0), (T,)), box, np.diag(box).copy(),
                       np.zeros(3, np.float32), spec.dt_ps)
     calc = SEDCalculator(traj, *spec.cells)
     _, vecs, grid_shape = k_request(calc, req)
@@ -156,164 +302,249 @@ def main():
     kw = {}
     if req.get("basis_atom_types"):
         kw["basis_atom_types"] = req["basis_atom_types"]
-    kw["summation_mode"] = args.summation
-    groups = calc._resolve_groups(None, kw.get("basis_atom_types"), args.summation)
-    intensity_out = args.summation == "incoherent" and len(groups) > 1
-    if not intensity_out and len(groups) > 1:
-        groups = [np.unique(np.concatenate(groups))]
-    dev_groups = calc._device_groups(groups)
+
+    def workload(summation):
+        groups = calc._resolve_groups(None, kw.get("basis_atom_types"), summation)
+        intensity = summation == "incoherent" and len(groups) > 1
+        if not intensity and len(groups) > 1:
+            groups = [np.unique(np.concatenate(groups))]
+        return groups, calc._device_groups(groups), intensity
+
+    groups, dev_groups, intensity_out = workload(args.summation)
     flags = _hip.F_INTENSITY if intensity_out else 0
     mean_pos = r0                         # mean of a static lattice; positions never leave the host
     n_sum_atoms = sum(len(g) for g in groups)
-    if world > 1 and not args.even_split:
+    mode = group.mode_for(K, T) if world > 1 else "single"
+    if mode == "k" and world > 1 and not args.even_split:
         # only rank 0 receives the result: it takes more k-vectors than the ranks that have to ship
         # their rows to it (dist.root_heavy_counts).  Cost model from the one-GPU measurements in
         # K1 time = max(one trajectory pass at the HBM-bound rate,
-        # 0.45 of that + n_k * atoms * frames / 3.4e13 units/s); one xGMI link per sender.
+        # 0.45 of that + n_k * atoms * frames / K1_UNITS_PER_S); one xGMI link per sender.
         floor_s = 12.0 * n_sum_atoms * T / HBM_BOUND_K1_BPS
         group.balance = dict(per_k_s=n_sum_atoms * T / K1_UNITS_PER_S, base_s=0.45 * floor_s, floor_s=floor_s,
                              per_k_bytes=(4.0 if intensity_out else 24.0) * T, link_bytes_per_s=XGMI_LINK_BPS,
                              block_k=64)          # 128-row M blocks of the projection kernel
+    # the trajectory, generated in HBM: all of it, or this rank's frames
+    t_begin, t_count = (group.my_frames(T) if mode == "frames" else (0, T))
+    synth.fill_device(engine, _hip.SLOT_VELOCITIES, spec, tables, t_begin, t_count)
 
-    def step():
-        group.project(_hip.SLOT_VELOCITIES, mean_pos, vecs, dev_groups, flags)
+    def step(dev_groups=dev_groups, flags=flags, intensity_out=intensity_out):
+        group.project(_hip.SLOT_VELOCITIES, mean_pos, vecs, dev_groups, flags, n_frames=T)
         if group.has_result:
             engine.finalize(T, K, intensity_out, fetch=False)
-            if not intensity_out:
+            if not intensity_out and not args.stub_engine:
                 engine._lib.psa_result_intensity(engine._h, None, 0)
 
-    for _ in range(args.warmup):
+    def timed(n_steps, **kwargs):
+        exchange.barrier()
+        engine.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step(**kwargs)
+        engine.synchronize()
+        exchange.barrier()
+        return max(exchange.allgather(time.perf_counter() - t0))
+
+    engine.oneoff_stats()
+    t0 = time.perf_counter()
+    step()
+    engine.synchronize()
+    first_step_s = time.perf_counter() - t0
+    oneoff = engine.oneoff_stats()                               # plan build, magnitude pass, plane build
+    for _ in range(max(0, args.warmup - 1)):
         step()
     engine.synchronize()
     engine.timings()
     engine.k1_stats()
-    exchange.barrier()
-    engine.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    engine.synchronize()
-    exchange.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = max(exchange.allgather(elapsed))
+    elapsed = timed(args.steps)
     stages = engine.timings()
     k1_n, k1_ms = engine.k1_stats()
+
+    # N > 1: the gathered result against a one-GPU recomputation on rank 0 (default on)
+    shard_check = None
+    if world > 1 and not args.no_check and not args.stub_engine:
+        gathered = None
+        if group.has_result:
+            gathered = engine.finalize(T, K, True) if intensity_out else engine.result_intensity(T, K)
+        exchange.barrier()
+        if rank == 0:
+            if mode == "frames":
+                synth.fill_device(engine, _hip.SLOT_VELOCITIES, spec, tables)        # now the whole trajectory
+            engine.project(_hip.SLOT_VELOCITIES, mean_pos, vecs, dev_groups, flags)
+            alone = engine.finalize(T, K, intensity_out)
+            alone = alone if intensity_out else np.sum(np.abs(alone) ** 2, axis=-1).astype(np.float32)
+            shard_check = float(np.max(np.abs(gathered - alone)) / np.max(np.abs(alone)))
+        exchange.barrier()
 
     if rank == 0:
         units = float(n_sum_atoms) * T * K
         ms_per_step = 1e3 * elapsed / args.steps
-        k_local = group.my_range(K)[1]
+        k_off, k_cnt = group.ranges(K, T)
+        k_local = K if mode == "frames" else int(k_cnt[0])
+        t_local = t_count
         # dominant kernel = the projection (K1); algorithmic work of ONE launch on this rank
-        per_launch_units = (float(n_sum_atoms) / len(groups)) * T * k_local
+        n_launch_atoms = float(n_sum_atoms) / len(groups)
+        per_launch_units = n_launch_atoms * t_local * k_local
         k1_avg_ms = k1_ms / max(1, k1_n)
         flops = FLOP_PER_UNIT * per_launch_units
-        algo_bytes = 12.0 * (n_sum_atoms / len(groups)) * T + 8.0 * k_local * (n_sum_atoms / len(groups)) \
-            + 24.0 * T * k_local
-        split = args.k1 != "mfma32"          # every velocity-mode group runs a split kernel
-        # the library's own rule (api.hip make_geom): "2 x f16" for velocity-mode groups with more
-        # than 16 k-vectors on this rank, "3 x bf16" for short k-lists
-        f16 = args.k1 == "auto" and k_local > 16
-        split_name = "2xf16" if f16 else "3xbf16" if split else ""
+        algo_bytes = 12.0 * n_launch_atoms * t_local + 8.0 * k_local * n_launch_atoms + 24.0 * t_local * k_local
+        # the library's rule (api.hip get_planes / make_geom): "2 x f16" for groups with more than 16
+        # k-vectors -- from cached planes ("auto") or splitting in the kernel -- "3 x bf16" below
+        if args.k1 == "mfma32":
+            products, kernel_name, dtype = 1, "k1_mfma_kernel (k-projection, exact-fp32 MFMA)", "f32"
+        elif args.k1 == "bf16x3" or k_local <= 16:
+            products, kernel_name = 6, "k1_split_kernel (k-projection, 3xbf16 split-precision MFMA, fp32-equivalent)"
+            dtype = "f32 (3xbf16 split MFMA, fp32 accumulate)"
+        else:
+            products = 3
+            kernel_name = ("k1_planes_kernel (k-projection from cached split planes, 2xf16 split-precision MFMA, "
+                           "fp32-equivalent)" if args.k1 == "auto"
+                           else "k1_pair_kernel (k-projection, 2xf16 split-precision MFMA, fp32-equivalent)")
+            dtype = "f32 (2xf16 split MFMA, fp32 accumulate)"
         # matrix-core ceiling for the ALGORITHMIC flop: the fp32 MFMA peak for the exact kernel; for a
         # split kernel the dense 16-bit peak over the MFMA products one fp32 product costs (3 or 6)
-        products = SPLIT_MFMA_FLOP_PER_UNIT["auto" if f16 else "bf16x3"] // FLOP_PER_UNIT if split else 1
-        peak_mfma = PEAK_BF16_MFMA_TFLOPS / products if split else PEAK_FP32_MFMA_TFLOPS
+        peak_mfma = PEAK_FP32_MFMA_TFLOPS if products == 1 else PEAK_16BIT_MFMA_TFLOPS / products
         t_mfma = flops / (peak_mfma * 1e12)
         t_hbm = algo_bytes / (PEAK_HBM_GBS * 1e9)
         bound = "mfma" if t_mfma >= t_hbm else "hbm"
+        k1_s = max(k1_avg_ms, 1e-9) * 1e-3
         if bound == "mfma":
-            achieved, peak, unit = flops / (k1_avg_ms * 1e-3) / 1e12, peak_mfma, "TFLOP/s"
+            achieved, peak, unit = flops / k1_s / 1e12, peak_mfma, "TFLOP/s"
         else:
-            achieved, peak, unit = algo_bytes / (k1_avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
-        kernel_name = ("k1_pair_kernel (k-projection, 2xf16 split-precision MFMA, fp32-equivalent)" if f16
-                       else f"k1_split_kernel (k-projection, 3xbf16 split-precision MFMA, fp32-equivalent)" if split
-                       else "k1_mfma_kernel (k-projection, exact-fp32 MFMA)")
-        roof_note = ("achieved = algorithmic 12 flop/unit (or algorithmic bytes) over the kernel time; mfma peak = "
-                     + (f"2500 TFLOP/s dense 16-bit MFMA / {products} products per fp32-equivalent product"
-                        if split else "157.3 TFLOP/s dense fp32 MFMA")
-                     + "; the side whose time at peak is longer is reported as the bound")
-        executed = None
-        if split:
-            issued = SPLIT_MFMA_FLOP_PER_UNIT["auto" if split_name == "2xf16" else "bf16x3"]
-            ex_rate = issued * per_launch_units / (k1_avg_ms * 1e-3) / 1e12
-            executed = {"what": f"16-bit MFMA flop actually issued ({issued // 12} "
-                                f"products per fp32 product)",
-                        "rate": ex_rate, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ex_rate / PEAK_BF16_MFMA_TFLOPS}
+            achieved, peak, unit = algo_bytes / k1_s / 1e9, PEAK_HBM_GBS, "GB/s"
         out = {
             "metric": "SED throughput (k-points*timesteps*atoms/s)",
-            "value": units * args.steps / elapsed,
+            "value": 0.0 if args.stub_engine else units * args.steps / elapsed,
             "unit": "k-points*timesteps*atoms/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": dtype, "data": "STUB ENGINE: orchestration test, nothing measured" if args.stub_engine else "synthetic",
             "config": {"workload": f"{args.config}: {N} atoms x {T} steps x {K} k-points, "
                                    f"{req.get('direction', req.get('plane'))} "
                                    f"{'k-path' if req['kind'] == 'path' else 'k-grid'}, {args.summation}"
                                    f"{', basis types ' + str(req['basis_atom_types']) if req.get('basis_atom_types') else ''}",
                        "atoms": N, "timesteps": T, "k_points": K, "atom_groups": len(groups),
-                       "output": "(T,K) float32 intensity" if intensity_out else "(T,K,3) complex64 + intensity",
-                       "parallelism": (f"k-shard x{world} ({'RCCL' if group.transport == 'rccl' else 'HOST-STAGED (RCCL unavailable)'}"
-                                       f" gather to rank 0; k-points per rank {group.ranges(K)[1].tolist()})") if world > 1 else "single GPU",
-                       "device": info["name"]},
+                       "output": ("(T,K) float32 intensity" if intensity_out else "(T,K,3) complex64 + intensity")
+                                 + ", left in HBM (end_to_end: on the host)",
+                       "parallelism": "single GPU" if world == 1 else
+                                      {"k": f"k-shard x{world}: every rank holds all {T} frames, k-points per rank "
+                                            f"{k_cnt.tolist()}, gather to rank 0",
+                                       "frames": f"frame-shard x{world}: {t_count} frames per rank, all {K} k-points projected "
+                                                 f"on them, all-to-all before the FFT (k rows per rank {k_cnt.tolist()}), "
+                                                 f"gather to rank 0"}[mode],
+                       "shard_mode": mode, "transport": "single" if world == 1 else group.transport,
+                       "k_points_per_rank": k_cnt.tolist(), "device": info["name"]},
             "roofline": {"kernel": kernel_name, "bound": bound,
                          "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
                          "traffic": None, "avg_launch_ms": k1_avg_ms, "launches": k1_n,
                          "algorithmic_flop_per_launch": flops, "algorithmic_bytes_per_launch": algo_bytes,
-                         "hbm_frac_if_bytes_bound": (algo_bytes / (k1_avg_ms * 1e-3) / 1e9) / PEAK_HBM_GBS,
-                         "vs_fp32_mfma_peak": flops / (k1_avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                         "note": roof_note},
+                         "hbm_frac_if_bytes_bound": (algo_bytes / k1_s / 1e9) / PEAK_HBM_GBS,
+                         "vs_fp32_mfma_peak": flops / k1_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "note": "achieved = algorithmic 12 flop/unit (or algorithmic bytes) of ONE launch on rank 0 over the "
+                                 "kernel's mean duration (HIP events on the library's stream); mfma peak = "
+                                 + (f"2500 TFLOP/s dense 16-bit MFMA / {products} MFMA products per fp32-equivalent product"
+                                    if products > 1 else "157.3 TFLOP/s dense fp32 MFMA")
+                                 + "; the side whose time at peak is longer is reported as the bound"},
             "stages_ms_per_step": {k: v / args.steps for k, v in stages.items()},
+            "first_step": {"wall_ms": 1e3 * first_step_s, "rocfft_plan_build_ms": oneoff["rocfft_plan"],
+                           "magnitude_pass_ms": oneoff["absmax"], "split_planes_build_ms": oneoff["split_planes"],
+                           "note": "first step after the trajectory is in HBM: run-time compiled rocFFT plan, one "
+                                   "largest-magnitude pass and the split-plane build, all cached afterwards"},
         }
-        if executed:
-            out["roofline"]["executed_mfma"] = executed
-        out["dtype"] = f"f32 ({split_name} split MFMA, fp32 accumulate)" if split else "f32"
-        # HBM-side traffic of K1 from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        if products > 1:
+            ex_rate = products * flops / k1_s / 1e12
+            out["roofline"]["executed_mfma"] = {
+                "what": f"16-bit MFMA flop actually issued ({products} products per fp32 product)",
+                "rate": ex_rate, "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ex_rate / PEAK_16BIT_MFMA_TFLOPS}
+        if shard_check is not None:
+            out["shard_check_max_rel"] = shard_check
+        # HBM-side traffic of K1 from the committed PMC passes of this round (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs; FETCH_SIZE doubled for 16-byte/lane streaming reads as
         # MI355X_MICROARCH.md prescribes; counts L2->fabric requests, Infinity-Cache hits included)
         # -- only when this run is the profiled workload
-        pmc = ROOT / "profiles" / ("r1g_C3_pmc_fetch_write.json" if f16 else "r1d_C3_pmc_fetch_write.json" if split
-                                   else "r1b_C3_pmc_fetch_write.json")
-        if args.config == "C3" and K == 256 and world == 1 and not intensity_out and pmc.exists():
+        pmc = ROOT / "profiles" / "r2_C3_pmc_fetch_write.json"
+        if (args.config == "C3" and K == 256 and world == 1 and not intensity_out and args.k1 == "auto"
+                and pmc.exists()):
             summ = json.loads(pmc.read_text())["k1_summary"]
             out["roofline"]["traffic"] = summ["fetch_bytes_corrected_x2"] + summ["write_bytes"]
             out["roofline"]["traffic_source"] = f"profiles/{pmc.name} (PMC, per launch)"
-        if world == 1 and not args.no_cpu_baseline:
-            cores = len(os.sched_getaffinity(0))
-            try:                                   # threads the BLAS under NumPy actually runs
-                from threadpoolctl import threadpool_info
-                blas = [i["num_threads"] for i in threadpool_info() if i.get("user_api") == "blas"]
-                if blas:
-                    cores = min(cores, max(blas))
-            except Exception:
-                pass
+
+        extras = world == 1 and not args.no_extras and not args.stub_engine
+        if extras:
+            # ---- the other summation mode of the same workload ------------------------------------------
+            other = "incoherent" if args.summation == "coherent" else "coherent"
+            o_groups, o_dev, o_int = workload(other)
+            if (o_int, len(o_groups)) != (intensity_out, len(groups)):
+                o_kw = dict(dev_groups=o_dev, flags=_hip.F_INTENSITY if o_int else 0, intensity_out=o_int)
+                for _ in range(3):
+                    step(**o_kw)                                  # (index-list planes are built on the 2nd use)
+                engine.synchronize()
+                engine.k1_stats()
+                o_steps = max(3, args.steps // 2)
+                o_elapsed = timed(o_steps, **o_kw)
+                o_n, o_ms = engine.k1_stats()
+                o_units = float(sum(len(g) for g in o_groups)) * T * K
+                out["variants"] = {other: {
+                    "ms_per_step": 1e3 * o_elapsed / o_steps, "value": o_units * o_steps / o_elapsed,
+                    "atom_groups": len(o_groups), "k1_launches_per_step": o_n / o_steps,
+                    "k1_avg_launch_ms": o_ms / max(1, o_n),
+                    "output": "(T,K) float32 intensity" if o_int else "(T,K,3) complex64 + intensity"}}
+            # ---- the drop-in API: SEDCalculator.calculate on the resident trajectory -> host ndarray ----
+            engine.adopt(_hip.SLOT_VELOCITIES, stand_in)
+            calc.attach(engine=engine)
+            import weakref
+            calc._mean_cache = (weakref.ref(pos_stand_in), mean_pos, _hip.Engine._fingerprint(pos_stand_in))
+            call_kw = dict(kw, summation_mode=args.summation)
+            mags = np.zeros(K, np.float32)
+            sed = calc.calculate(mags, vecs, k_grid_shape=grid_shape, **call_kw)       # page-locks the result buffer
+            del sed
+            walls = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                sed = calc.calculate(mags, vecs, k_grid_shape=grid_shape, **call_kw)
+                walls.append(time.perf_counter() - t0)
+                assert isinstance(sed.sed, np.ndarray) and sed.sed.shape[:2] == (T, K)
+                del sed
+            e2e = float(np.median(walls))
+            out["end_to_end"] = {
+                "what": "psa_amd.SEDCalculator.calculate(k_mags, k_vecs, ...) on the trajectory resident in HBM, returning "
+                        "the SED with .sed as a host ndarray (D2H into recycled page-locked memory included)",
+                "ms": 1e3 * e2e, "min_ms": 1e3 * min(walls), "value": units / e2e, "unit": "k-points*timesteps*atoms/s",
+                "result_bytes": (4 if intensity_out else 24) * T * K,
+                "note": "mean positions of the static lattice are cached per positions array (first call: one "
+                        "np.mean pass, as in the reference on every call); first-call costs: first_step above plus "
+                        "the upload, measured at configuration-2 size in tests/test_gpu_planes_stream.py "
+                        "(54 GB/s through the staging pipeline, projection overlapped)"}
+        if world == 1 and not args.no_cpu_baseline and not args.stub_engine:
             n_frames = args.cpu_frames or int(min(T, max(64, 2 ** int(np.log2(1.0e11 / (n_sum_atoms * K))))))
-            rate, secs, vel, ref_int, mean_sample = cpu_baseline(spec, tables, r0, types, vecs, kw, n_frames)
+            call_kw = dict(kw, summation_mode=args.summation)
+            n_units, times, vel, ref_int, mean_sample = cpu_baseline(spec, tables, r0, types, vecs, call_kw, n_frames)
             # parity of the HIP path on the very same sample
             engine.ensure_resident(_hip.SLOT_VELOCITIES, vel)
             engine.project(_hip.SLOT_VELOCITIES, mean_sample, vecs, dev_groups, flags)
             got = engine.finalize(n_frames, K, intensity_out)
             got_int = got if intensity_out else np.sum(np.abs(got) ** 2, axis=-1).astype(np.float32)
             err = float(np.max(np.abs(got_int - ref_int)) / np.max(np.abs(ref_int)))
+            rate = n_units / min(times)
+            gpu_rate = out.get("end_to_end", {}).get("value", out["value"])
             out["cpu_baseline"] = {
-                "value": rate, "unit": "k-points*timesteps*atoms/s", "cores": cores, "kind": "port",
+                "value": rate, "unit": "k-points*timesteps*atoms/s", "cores": len(_SOCKET_CPUS), "kind": "port",
+                "median_value": n_units / float(np.median(times)), "reps": len(times),
+                "seconds": {"min": min(times), "median": float(np.median(times))},
+                "cpu_model": cpu_model(), "sockets_visible": _N_SOCKETS,
+                "pinning": f"os.sched_setaffinity to the {len(_SOCKET_CPUS)} physical cores of one socket visible to this "
+                           f"process; OPENBLAS/OMP/MKL_NUM_THREADS={len(_SOCKET_CPUS)} set before NumPy loaded",
                 "sample": f"first {n_frames} of {T} frames, all {N} atoms, all {K} k-points "
-                          f"(oracle/psa_oracle.py: NumPy einsum+pocketfft restatement, best of 2, {secs:.1f} s)",
-                "speedup_vs_cpu": units * args.steps / elapsed / rate,
+                          f"(oracle/psa_oracle.py: NumPy einsum+pocketfft restatement of the reference path)",
+                "speedup_vs_cpu": gpu_rate / rate,
+                "speedup_basis": "end_to_end.value (result on the host, like the CPU path's)" if "end_to_end" in out
+                                 else "value (result left in HBM)",
                 "parity_max_rel_intensity_on_sample": err}
-        if args.check and group.has_result:
-            gathered = engine.result_intensity(T, K) if not intensity_out else engine.finalize(T, K, True)
-            engine.project(_hip.SLOT_VELOCITIES, mean_pos, vecs, dev_groups, flags)
-            alone = engine.finalize(T, K, intensity_out)
-            alone = alone if intensity_out else np.sum(np.abs(alone) ** 2, axis=-1).astype(np.float32)
-            out["shard_check_max_rel"] = float(np.max(np.abs(gathered - alone)) / np.max(np.abs(alone)))
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    exchange.barrier()
     group.close()
     engine.close()
-    if world > 1:
-        import torch.distributed as td
-        td.destroy_process_group()
 
 
 if __name__ == "__main__":

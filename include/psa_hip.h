@@ -209,6 +209,10 @@ int psa_last_timings(psa_ctx* ctx, double* ms /* [8] */);
 /* number of projection-kernel launches and their summed duration (HIP events on
  * the context's stream) since the last call of this function */
 int psa_k1_stats(psa_ctx* ctx, int64_t* launches, double* total_ms);
+/* host wall clock (ms) of work that is done once and then cached, summed since the last call:
+ * [0] rocFFT plan builds (run-time compiled per (T, batch))  [1] largest-magnitude passes
+ * [2] split-plane builds  [3] trajectory uploads (psa_data_upload / psa_sed_project_upload) */
+int psa_oneoff_stats(psa_ctx* ctx, double* ms /* [4] */);
 
 /* diagnostics for tests: the phase table of one group as (K,N_g) complex64, and the
  * pre-FFT projection q as (K,3,T) complex64 */

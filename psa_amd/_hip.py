@@ -66,6 +66,7 @@ SIGNATURES = {
     "psa_result_chiral_phase": (C.c_int, [_ctx, C.c_int, C.c_int, _f32p, C.c_size_t]),
     "psa_last_timings": (C.c_int, [_ctx, C.POINTER(C.c_double)]),
     "psa_k1_stats": (C.c_int, [_ctx, _i64p, C.POINTER(C.c_double)]),
+    "psa_oneoff_stats": (C.c_int, [_ctx, C.POINTER(C.c_double)]),
     "psa_debug_phase_table": (C.c_int, [_ctx, _f32p, _f32p, C.c_int64, _i32p, C.c_int64,
                                         C.c_int64, C.c_void_p]),
     "psa_debug_project_only": (C.c_int, [_ctx, C.c_int, _f32p, _f32p, C.c_int64, _i32p,
@@ -300,10 +301,11 @@ class Engine:
     def is_resident(self, slot: int, array: np.ndarray) -> bool:
         """True if this very array (same object, same buffer, same sampled contents) is what the
         slot holds."""
-        a = self._as_device_layout(slot, array)
         held = self._resident.get(slot)
-        return (held is not None and held[0] is not None and held[0]() is a
-                and held[1:3] == (a.ctypes.data, a.shape) and held[3] == self._fingerprint(a))
+        if held is None or held[0] is None:
+            return False
+        a = array if held[0]() is array else self._as_device_layout(slot, array)
+        return (held[0]() is a and held[1:3] == (a.ctypes.data, a.shape) and held[3] == self._fingerprint(a))
 
     def _note_resident(self, slot: int, a: np.ndarray):
         # a weak reference, not id(): a freed array's id and buffer can be reused
@@ -454,6 +456,21 @@ class Engine:
         ms = (C.c_double * 8)()
         _check(self._lib.psa_last_timings(self._h, ms), "psa_last_timings")
         return dict(zip(TIMING_NAMES, list(ms)))
+
+    def oneoff_stats(self) -> dict:
+        """Host wall clock (ms) of once-per-array / once-per-shape work since the last call."""
+        ms = (C.c_double * 4)()
+        _check(self._lib.psa_oneoff_stats(self._h, ms), "psa_oneoff_stats")
+        return dict(zip(("rocfft_plan", "absmax", "split_planes", "upload"), list(ms)))
+
+    def adopt(self, slot: int, array: np.ndarray):
+        """Declare that the slot's device-generated contents (alloc + fill_synthetic) ARE `array` as
+        far as residency goes: `calculate` on a Trajectory holding `array` then finds it resident.
+        For benchmarks whose trajectory exists only in HBM (`array` can be a zero-stride stand-in)."""
+        T, N = self.shape(slot)
+        if tuple(array.shape) != (T, N, 3) or array.dtype != np.float32 or not array.flags.c_contiguous and array.strides != (0, 0, 0):
+            raise ValueError("stand-in must be a float32 (T, N, 3) array of the slot's shape")
+        self._note_resident(slot, array)
 
     def k1_stats(self):
         n, ms = C.c_int64(0), C.c_double(0.0)

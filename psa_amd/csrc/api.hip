@@ -1,6 +1,7 @@
 // C ABI of libpsa_hip.so (declared in include/psa_hip.h): context, trajectory residency,
 // the project -> FFT -> epilogue pipeline, k-shard gather over RCCL.
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +47,13 @@ void DevBuf::release() {
 }
 
 namespace {
+
+struct HostTimer {                                    // adds its lifetime to one of ctx->oneoff_ms
+    double*                               into;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit HostTimer(double* into_) : into(into_) {}
+    ~HostTimer() { *into += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 struct Guard {
     std::lock_guard<std::mutex> lk;
@@ -115,7 +123,8 @@ int get_plan(psa_ctx* c, int64_t T, int64_t batch, FftPlan** out) {
     auto key = std::make_pair(T, batch);
     auto it = c->plans.find(key);
     if (it == c->plans.end()) {
-        FftPlan p;
+        HostTimer ht(&c->oneoff_ms[0]);
+        FftPlan   p;
         size_t  len = (size_t)T;
         PSA_FFT_CHECK(rocfft_plan_create(&p.plan, rocfft_placement_inplace,
                                          rocfft_transform_type_complex_forward,
@@ -145,6 +154,7 @@ int run_fft(psa_ctx* c, float2* data, int64_t T, int64_t batch) {
 int slot_absmax(psa_ctx* c, int slot) {
     DataSlot& s = c->slot[slot];
     if (s.absmax_known) return PSA_OK;
+    HostTimer ht(&c->oneoff_ms[1]);
     PSA_TRY(c->d_absmax.reserve(sizeof(unsigned)));
     PSA_TRY(launch_absmax_bits(c, s.buf.as<float>(), s.T * s.N * 3, c->d_absmax.as<unsigned>()));
     PSA_HIP_CHECK(hipMemcpyAsync(&s.absmax_bits, c->d_absmax.ptr, sizeof(unsigned), hipMemcpyDeviceToHost,
@@ -159,6 +169,7 @@ int slot_absmax(psa_ctx* c, int slot) {
 int group_absmax(psa_ctx* c, int slot, const int32_t* h_idx, int64_t n_g, unsigned* bits) {
     DataSlot& s = c->slot[slot];
     if (!s.blocks_known) {
+        HostTimer    ht(&c->oneoff_ms[1]);
         const size_t n_blocks = (size_t)((s.N + 31) / 32);
         PSA_TRY(c->d_absmax.reserve(n_blocks * sizeof(unsigned)));
         PSA_TRY(launch_absmax_blocks(c, s.buf.as<float>(), s.T, s.N, c->d_absmax.as<unsigned>()));
@@ -267,7 +278,12 @@ int get_planes(psa_ctx* c, int slot, const int* d_idx, const int32_t* h_idx, int
         (void)hipGetLastError();
         return PSA_OK;
     }
-    PSA_TRY(launch_split_planes(c, s.buf.as<float>(), d_idx, ps->buf.ptr, s.T, s.N, (int)n_g, A_pad, vscale));
+    {
+        HostTimer ht(&c->oneoff_ms[2]);                 // timed: the stream is drained once per set
+        PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        PSA_TRY(launch_split_planes(c, s.buf.as<float>(), d_idx, ps->buf.ptr, s.T, s.N, (int)n_g, A_pad, vscale));
+        PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
     ps->slot = slot;
     ps->generation = s.generation;
     ps->all_atoms = all;
@@ -487,6 +503,7 @@ int staged_upload(psa_ctx* c, float* dev, const float* host, int64_t T, int64_t 
     frames = std::min(frames, T);
     PSA_TRY(stager_init(c, (size_t)frames * row));
     Stager&                     st = c->stager;
+    HostTimer                   ht(&c->oneoff_ms[3]);
     std::lock_guard<std::mutex> pool_lock(g_copy_pool_mutex);
     std::vector<hipEvent_t>     landed;
     int                         rc = PSA_OK;
@@ -1213,6 +1230,17 @@ int psa_last_timings(psa_ctx* c, double* ms) {
     for (int i = 0; i < PSA_T_COUNT; ++i) {
         ms[i] = ts.acc[i];
         ts.acc[i] = 0.0;
+    }
+    return PSA_OK;
+}
+
+int psa_oneoff_stats(psa_ctx* c, double* ms) {
+    PSA_TRY(enter(c));
+    PSA_REQUIRE(ms != nullptr, "null output");
+    Guard guard(c);
+    for (int i = 0; i < 4; ++i) {
+        ms[i] = c->oneoff_ms[i];
+        c->oneoff_ms[i] = 0.0;
     }
     return PSA_OK;
 }

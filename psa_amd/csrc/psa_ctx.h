@@ -200,6 +200,8 @@ struct psa_ctx {
     std::map<std::pair<int64_t, int64_t>, psa::FftPlan> plans;   // (T, batch)
 
     psa::TimingState timing;
+    double oneoff_ms[4] = {0, 0, 0, 0};   // host wall clock of work done once: rocFFT plan builds, magnitude passes,
+                                          // plane builds, trajectory uploads (psa_oneoff_stats)
     psa::DevBuf      d_sync;     // one float for the RCCL barrier
 
     ncclComm_t comm = nullptr;
