@@ -91,6 +91,27 @@ __device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_byte_addr)
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory");
 }
+// N consecutive 1-KiB pieces in ONE addressing setup: uniform 64-bit base in SGPRs + a 32-bit
+// per-lane offset; piece i adds the instruction offset 1024 i, which the hardware applies to the
+// global address AND to the LDS address (tools/probes/dma_offset.hip).  One M0 write, no VALU.
+template <int N>
+__device__ __forceinline__ void lds_dma16_group(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+    static_assert(N >= 1 && N <= 4, "instruction offsets reach 4095");
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    if constexpr (N == 1)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(dst) : "memory");
+    else if constexpr (N == 2)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sbase), "s"(dst) : "memory");
+    else if constexpr (N == 3)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:1024\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048"
+                     ::"v"(voff), "s"(sbase), "s"(dst) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:1024\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(sbase), "s"(dst) : "memory");
+}
 // 12 bytes per lane, landing at dst + lane * 16
 __device__ __forceinline__ void lds_dma12(const void* g, unsigned lds_byte_addr) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);

@@ -25,8 +25,18 @@
 //   1: the second row half (waves 4-7, the SIMD partners of 0-3) issues its DMA half a stage later
 //   2: s_setprio 1 for waves 4-7      4: DMA pieces spread over the row-tile regions
 //   8: B-fragment reads spread over the regions   16: no sched_barrier between the regions
+//  32: DMA addressed as SGPR base + per-lane 32-bit offset, the pieces of a group told apart by the
+//      instruction offset (it moves the global AND the LDS address: tools/probes/dma_offset.hip) --
+//      one M0 write per group and no 64-bit VALU address arithmetic
+//  64: main loop unrolled over the slot ring (LDS addresses become instruction offsets)
 #ifndef PSA_K1P_X
-#define PSA_K1P_X 19        // product build: stagger + priority + free scheduling (14.9 ms vs 16.0 at 0, configuration 3)
+#define PSA_K1P_X 51        // product build: 1 + 2 + 16 + 32 (64 measured 3 % slower)
+#endif
+#ifndef PSA_K1P_POS
+#define PSA_K1P_POS -1      // row tile after which waves 4-7 issue their DMA (-1: the middle one)
+#endif
+#ifndef PSA_K1P_PRIO
+#define PSA_K1P_PRIO 1      // which row half runs at s_setprio 1 (bit 2 of PSA_K1P_X)
 #endif
 
 namespace psa {
@@ -84,6 +94,10 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
     const int            pw = C::P_PIECES >= 8 ? w * C::P_DMA : (w & 3);
     const unsigned char* pp = reinterpret_cast<const unsigned char*>(Pb) + (size_t)mb * n_stage * C::P_STAGE_BYTES +
                               1024 * pw + 16 * lane;
+    // the same as (uniform base, per-lane offset) pairs for the SGPR-base form
+    const unsigned char* vbase = reinterpret_cast<const unsigned char*>(planes) + (size_t)fg * n_stage * C::V_GROUP_BYTES;
+    const unsigned char* pbase = reinterpret_cast<const unsigned char*>(Pb) + (size_t)mb * n_stage * C::P_STAGE_BYTES;
+    const unsigned       v_voff = 1024 * (wh * C::V_DMA) + 16 * lane, p_voff = 1024 * pw + 16 * lane;
     // piece i of this wavefront's BATCH for stage st (clamped) -> slot: P' pieces first, then V
     auto dma_piece = [&](int i, int st, int slot) {
         const int      sc = st < last ? st : last;
@@ -97,8 +111,16 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
         }
     };
     auto dma_stage = [&](int st, int slot) {
+        if constexpr ((PSA_K1P_X & 32) != 0) {
+            const int      sc = st < last ? st : last;
+            const unsigned dst = lds0 + slot * C::STAGE_BYTES;
+            lds_dma16_group<C::P_DMA>(pbase + (size_t)sc * C::P_STAGE_BYTES, p_voff, dst + 1024 * pw);
+            lds_dma16_group<C::V_DMA>(vbase + (size_t)sc * C::V_GROUP_BYTES, v_voff,
+                                      dst + C::P_STAGE_BYTES + wf * C::V_GROUP_BYTES + 1024 * (wh * C::V_DMA));
+        } else {
 #pragma unroll
-        for (int i = 0; i < C::BATCH; ++i) dma_piece(i, st, slot);
+            for (int i = 0; i < C::BATCH; ++i) dma_piece(i, st, slot);
+        }
     };
 
     // ---- LDS read addresses: both images use the 64-byte rows / swizzled 16-byte slots of k1_f16.h
@@ -130,7 +152,7 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
         }
 
     if constexpr ((PSA_K1P_X & 2) != 0) {
-        if (wh == 1) __builtin_amdgcn_s_setprio(1);
+        if (wh == PSA_K1P_PRIO) __builtin_amdgcn_s_setprio(1);
     }
     // ---- prologue: stages 0 .. RING-1 in flight; stage 0 into registers --------------------------
 #pragma unroll
@@ -154,9 +176,10 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
     // One stage: slot holds stage s (in registers already), slot1 stage s+1 (landed).  The DMA of
     // stage s+RING goes into slot; the B fragments of stage s+1 are read at the top, each row tile's
     // A fragments right behind the MFMAs that consumed the old ones.
-    auto stage = [&](auto par_c, auto restart_c, int s, int slot) {
+    auto stage = [&](auto par_c, auto restart_c, int s, auto slot_c) {
         constexpr int  par = decltype(par_c)::value;
         constexpr bool restart = decltype(restart_c)::value;
+        const int      slot = slot_c;                  // an int, or an integral_constant (unrolled loop)
         const int      slot1 = slot == C::RING - 1 ? 0 : slot + 1;
         constexpr bool STAGGER = (PSA_K1P_X & 1) != 0, SPREAD_DMA = (PSA_K1P_X & 4) != 0,
                        SPREAD_B = (PSA_K1P_X & 8) != 0, FREE = (PSA_K1P_X & 16) != 0;
@@ -179,7 +202,8 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
             if constexpr (!FREE) __builtin_amdgcn_sched_barrier(0);
             read_a_tile(mt, slot1);
             if constexpr (STAGGER && !SPREAD_DMA) {
-                if (mt == (MT16 - 1) / 2 && wh == 1) dma_stage(s + C::RING, slot);
+                if (mt == (PSA_K1P_POS < 0 ? (MT16 - 1) / 2 : (PSA_K1P_POS < MT16 ? PSA_K1P_POS : MT16 - 1)) && wh == 1)
+                    dma_stage(s + C::RING, slot);
             }
             if constexpr (!FREE) __builtin_amdgcn_sched_barrier(0);
         }
@@ -188,9 +212,26 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    int  slot = 0;                                     // s % RING
+    int s0 = 0;
+    if constexpr ((PSA_K1P_X & 64) != 0) {
+        // main loop: one fold period per iteration, slots and parities compile-time
+        // (RING 3: 6 stages, RING 4: 8 -- both within the <= FOLD stages a chain may run)
+        constexpr int PERIOD = C::RING == 3 ? 6 : 8;
+        static_assert(PERIOD <= C::FOLD && PERIOD % C::RING == 0 && PERIOD % 2 == 0, "period");
+        for (; s0 + PERIOD <= n_stage; s0 += PERIOD) {
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (stage(std::integral_constant<int, (I & 1)>{}, std::bool_constant<I == 0>{}, s0 + I,
+                       std::integral_constant<int, I % C::RING>{}), ...);
+            }(std::make_integer_sequence<int, PERIOD>{});
+#pragma unroll
+            for (int mt = 0; mt < MT16; ++mt)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) lo[mt][c] += hi[mt][c];
+        }
+    }
+    int  slot = 0;                                     // s % RING  (s0 is a multiple of RING)
     auto next_slot = [&]() { slot = slot == C::RING - 1 ? 0 : slot + 1; };
-    for (int s = 0; s < n_stage;) {                    // n_stage is even; a chain is an even number of stages
+    for (int s = s0; s < n_stage;) {                   // n_stage is even; a chain is an even number of stages
         const int len = n_stage - s < C::FOLD ? n_stage - s : C::FOLD;
         stage(I0{}, std::true_type{}, s, slot);
         next_slot();

@@ -17,11 +17,12 @@ mkdir -p "$OUT"
 if [ "$mode" = build ]; then
   make -C "$SRC" >/dev/null
   for x in "$@"; do
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I"$ROOT/include" -I"$SRC" -fno-fast-math \
-      -ffp-contract=on -fno-slp-vectorize -D$MACRO=$x -c "$SRC/$KERNEL.hip" -o "$OUT/${KERNEL}_x$x.o" 2>/dev/null
+    /opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -I"$ROOT/include" -I"$SRC" -fno-fast-math \
+      -ffp-contract=on -fno-slp-vectorize -D$MACRO=$x $EXTRA_DEFS -c "$SRC/$KERNEL.hip" -o "$OUT/${KERNEL}_x$x.o" 2>/dev/null
     objs=$(sed -n 's/^SRCS := //p' "$SRC/Makefile" | tr ' ' '\n' | grep -v "^$KERNEL.hip" | sed "s#\(.*\)\.hip#$SRC/build/\1.o#")
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$OUT/libpsa_hip_x$x.so" $objs "$OUT/${KERNEL}_x$x.o" \
       -L/opt/rocm/lib -lrocfft -lrccl -Wl,-rpath,/opt/rocm/lib 2>/dev/null
+    [ -n "$TAG" ] && mv "$OUT/libpsa_hip_x$x.so" "$OUT/libpsa_hip_x$TAG.so" && x=$TAG
     echo "built $OUT/libpsa_hip_x$x.so"
   done
 else
