@@ -427,9 +427,20 @@ class Engine:
         return out
 
     def calculate(self, slot, mean_pos_all, k_vectors, groups=None, flags=0) -> np.ndarray:
+        """project + finalize in one library call (psa_sed_calculate): a complex result of a long
+        k-list is produced block by block, each block's D2H copy overlapping the next projection."""
         T, _ = self.shape(slot)
-        self.project(slot, mean_pos_all, k_vectors, groups, flags)
-        return self.finalize(T, len(k_vectors), bool(flags & F_INTENSITY))
+        mean = _as_f32(mean_pos_all, (3,))
+        kv = _as_f32(k_vectors, (3,))
+        idx, off, G = pack_groups(groups)
+        K = kv.shape[0]
+        out = pinned_empty((T, K), np.float32) if flags & F_INTENSITY else pinned_empty((T, K, 3), np.complex64)
+        _check(self._lib.psa_sed_calculate(
+            self._h, slot, _f32(mean), _f32(kv), K,
+            idx.ctypes.data_as(_i32p) if idx is not None else None,
+            off.ctypes.data_as(_i64p) if off is not None else None, G, flags,
+            out.ctypes.data_as(C.c_void_p), out.nbytes), "psa_sed_calculate")
+        return out
 
     def slab_read(self, row0: int, nrows: int, T: int, intensity: bool) -> np.ndarray:
         out = np.empty((nrows, T), np.float32) if intensity else np.empty((nrows, 3, T), np.complex64)

@@ -159,11 +159,14 @@ class SEDCalculator:
             T = self.traj.n_frames
             if self._shard is not None and self._shard.nranks > 1:
                 return self._shard.run(slot, data, mean_pos_all, k_vectors, groups, flags, T, fetch)
-            if eng.is_resident(slot, data):
-                eng.project(slot, mean_pos_all, k_vectors, groups, flags)
-            else:                            # first call on this array: upload and project, overlapped
+            if not eng.is_resident(slot, data):
+                # first call on this array: upload and project, overlapped
                 eng.project_upload(slot, data, mean_pos_all, k_vectors, groups, flags)
-            return eng.finalize(T, K, intensity, fetch)
+                return eng.finalize(T, K, intensity, fetch)
+            if fetch:                        # one library call; long complex results leave block by block
+                return eng.calculate(slot, mean_pos_all, k_vectors, groups, flags)
+            eng.project(slot, mean_pos_all, k_vectors, groups, flags)
+            return eng.finalize(T, K, intensity, False)
 
     # ------------------------------------------------------------------ the seam
     def _calculate_sed_for_group(self, k_vectors_3d: np.ndarray, group_atom_indices: np.ndarray,

@@ -351,18 +351,19 @@ int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, const int* d_i
 
 // phase table of one group in the image its projection kernel wants (+ the group's mean positions
 // for the subtract-while-staging kernels)
-int prepare_phase(psa_ctx* c, const int* d_idx, const ProjGeom& g, bool disp) {
+int prepare_phase(psa_ctx* c, const int* d_idx, const ProjGeom& g, bool disp, int64_t k_first = 0) {
+    const float* d_kvec = c->d_kvec.as<float>() + 3 * k_first;         // the launch's k-vectors within the uploaded list
     const bool f16 = g.split == 2 || g.split == 4, bf16 = g.split == 3;
     PSA_TRY(c->d_phase.reserve(f16    ? pf16_table_bytes(g.M_pad, g.A_pad)
                                : bf16 ? pb_table_bytes(g.M_pad, g.A_pad)
                                       : p_table_floats(g.M_pad, g.A_pad) * sizeof(float)));
     StageTimer st(c, PSA_T_PHASE);
     if (f16)
-        PSA_TRY(launch_phase_table_f16(c, c->d_kvec.as<float>(), c->d_mean_all.as<float>(), d_idx, c->d_phase.ptr, g));
+        PSA_TRY(launch_phase_table_f16(c, d_kvec, c->d_mean_all.as<float>(), d_idx, c->d_phase.ptr, g));
     else if (bf16)
-        PSA_TRY(launch_phase_table_split(c, c->d_kvec.as<float>(), c->d_mean_all.as<float>(), d_idx, c->d_phase.ptr, g));
+        PSA_TRY(launch_phase_table_split(c, d_kvec, c->d_mean_all.as<float>(), d_idx, c->d_phase.ptr, g));
     else
-        PSA_TRY(launch_phase_table(c, c->d_kvec.as<float>(), c->d_mean_all.as<float>(), d_idx, c->d_phase.as<float>(), g));
+        PSA_TRY(launch_phase_table(c, d_kvec, c->d_mean_all.as<float>(), d_idx, c->d_phase.as<float>(), g));
     if (disp) {
         PSA_TRY(c->d_mean_g.reserve((size_t)g.A_pad * 3 * sizeof(float)));
         PSA_TRY(launch_gather_mean(c, c->d_mean_all.as<float>(), d_idx, c->d_mean_g.as<float>(), g));
@@ -622,6 +623,8 @@ int psa_destroy(psa_ctx* c) {
         for (auto& ps : c->planes) ps->buf.release();
         c->planes.clear();
         stager_release(c);
+        if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
+        if (c->d2h_ready) (void)hipEventDestroy(c->d2h_ready);
         for (DevBuf* b : {&c->d_kvec, &c->d_mean_all, &c->d_idx, &c->d_mean_g, &c->d_phase, &c->d_qwork,
                           &c->d_fft_work, &c->d_tables, &c->d_absmax, &c->d_slab, &c->d_out, &c->d_aux, &c->d_sync,
                           &c->d_qrows, &c->d_stage, &c->d_bin})
@@ -1072,7 +1075,7 @@ int psa_sed_finalize(psa_ctx* c, void* out_host, size_t out_bytes) {
         if (c->res_intensity)
             PSA_TRY(launch_transpose_f32(c, c->d_slab.as<float>(), c->d_out.as<float>(), T, K));
         else
-            PSA_TRY(launch_scale_transpose_c64(c, c->d_slab.as<float2>(), c->d_out.as<float2>(), T, K));
+            PSA_TRY(launch_scale_transpose_c64(c, c->d_slab.as<float2>(), c->d_out.as<float2>(), T, K, K, 0));
     }
     c->out_valid = true;
     if (out_host) {
@@ -1083,10 +1086,105 @@ int psa_sed_finalize(psa_ctx* c, void* out_host, size_t out_bytes) {
     return PSA_OK;
 }
 
+// Blocks of k-vectors when a complex result is produced block by block so that the D2H copy of one
+// block runs while the next is projected.  r = (D2H time per k-vector) / (projection time per
+// k-vector) = (24 T / 55 GB/s) / (N_g T / 4.3e13 units/s) = 1.9e4 / N_g decides the shape:
+//   r < 1  (projection-bound, e.g. configuration 3): what stays exposed is the LAST block's copy ->
+//          one large block (efficient projection) and a last block of one 64-vector M block;
+//   r >= 1 (copy-bound, e.g. the 2500-point grid on 8192 atoms): what stays exposed is the FIRST
+//          block's projection -> a first block of 128, then blocks of 512.
+// Lists shorter than 192 are not split (every block is at least one M block of 64).
+static std::vector<int64_t> pipeline_blocks(int64_t K, int64_t n_g) {
+    std::vector<int64_t> b;
+    if (K < 192) {
+        b.push_back(K);
+    } else if (1.9e4 / (double)std::max<int64_t>(n_g, 1) < 1.0) {
+        b.push_back(K - 64);
+        b.push_back(64);
+    } else {
+        b.push_back(128);
+        for (int64_t k0 = 128; k0 < K; k0 += 512) b.push_back(std::min<int64_t>(512, K - k0));
+        if (b.back() < 64 && b.size() > 2) {             // fold a sliver into its neighbour
+            b[b.size() - 2] += b.back();
+            b.pop_back();
+        }
+    }
+    return b;
+}
+
+// Complex result of one group, all K on this device, straight to the host: per block of k-vectors
+// project -> FFT -> scale/transpose into its columns of (T, K, 3) -> 2-D D2H on a copy stream
+// (full PCIe rate at >= 1.5-KB rows: tools/probes/d2h_2d.hip), overlapped with the next block.
+static int calculate_pipelined(psa_ctx* c, const ProjectArgs& a, void* out_host) {
+    int       slot = a.slot;
+    const int64_t K = a.K_total;
+    PSA_TRY(check_slot(c, slot));
+    const int64_t T = c->slot[slot].T, N = c->slot[slot].N;
+    bool          disp = (a.flags & PSA_F_DISPLACEMENTS) != 0;
+    PSA_TRY(check_project_args(c, a, N));
+    char*  rows = nullptr;
+    size_t row_bytes = 0;
+    PSA_TRY(begin_result(c, T, K, 0, false, &rows, &row_bytes));
+    PSA_TRY(upload_project_inputs(c, a, N));
+    PSA_TRY(materialise_displacements(c, &slot, &disp, a.mean_pos_all));
+    PSA_TRY(c->d_out.reserve(result_bytes(c)));
+    if (!c->d2h_stream) PSA_HIP_CHECK(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+    if (!c->d2h_ready) PSA_HIP_CHECK(hipEventCreateWithFlags(&c->d2h_ready, hipEventDisableTiming));
+    const int64_t  n_g = a.group_idx ? (a.group_off[1] - a.group_off[0]) : N;
+    const int*     d_idx = a.group_idx ? c->d_idx.as<int>() : nullptr;
+    const int32_t* h_idx = a.group_idx ? a.group_idx : nullptr;
+    if (n_g == 0) {
+        std::memset(out_host, 0, result_bytes(c));
+        PSA_HIP_CHECK(hipMemsetAsync(c->d_out.ptr, 0, result_bytes(c), c->stream));
+        PSA_HIP_CHECK(hipMemsetAsync(rows, 0, row_bytes * (size_t)K, c->stream));
+        c->out_valid = true;
+        return PSA_OK;
+    }
+    PlaneSet* ps = nullptr;
+    if (!disp) PSA_TRY(get_planes(c, slot, d_idx, h_idx, n_g, K, &ps));
+    const size_t pitch = (size_t)K * 3 * sizeof(float2);
+    int64_t      k0 = 0;
+    for (const int64_t nk : pipeline_blocks(K, n_g)) {
+        float2* d_q = (float2*)(rows + row_bytes * (size_t)k0);
+        ProjGeom      g;
+        PSA_TRY(make_geom(c, slot, nk, n_g, d_idx, h_idx, disp, ps, 0, &g));
+        PSA_TRY(prepare_phase(c, d_idx, g, disp, k0));
+        PSA_TRY(launch_projection(c, slot, d_idx, g, disp, ps, d_q, T, 0, T));
+        {
+            StageTimer st(c, PSA_T_FFT);
+            PSA_TRY(run_fft(c, d_q, T, 3 * nk));
+        }
+        {
+            StageTimer st(c, PSA_T_TRANSPOSE);
+            PSA_TRY(launch_scale_transpose_c64(c, d_q, c->d_out.as<float2>(), T, nk, K, k0));
+        }
+        PSA_HIP_CHECK(hipEventRecord(c->d2h_ready, c->stream));
+        PSA_HIP_CHECK(hipStreamWaitEvent(c->d2h_stream, c->d2h_ready, 0));
+        const size_t off = (size_t)k0 * 3 * sizeof(float2), width = (size_t)nk * 3 * sizeof(float2);
+        PSA_HIP_CHECK(hipMemcpy2DAsync((char*)out_host + off, pitch, (const char*)c->d_out.ptr + off, pitch, width, (size_t)T,
+                                       hipMemcpyDeviceToHost, c->d2h_stream));
+        k0 += nk;
+    }
+    c->out_valid = true;
+    PSA_HIP_CHECK(hipStreamSynchronize(c->d2h_stream));
+    PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PSA_OK;
+}
+
 int psa_sed_calculate(psa_ctx* c, int slot, const float* mean_pos_all, const float* k_vectors,
                       int64_t K, const int32_t* group_idx, const int64_t* group_off, int32_t G,
                       int32_t flags, void* out_host, size_t out_bytes) {
     PSA_REQUIRE(K >= 1, "need at least one k-vector");
+    if (out_host && !(flags & PSA_F_INTENSITY) && G == 1 && K >= 192 && c && c->k1_selector == PSA_K1_AUTO) {
+        PSA_TRY(enter(c));
+        Guard guard(c);
+        PSA_TRY(check_slot(c, slot));
+        const size_t bytes = (size_t)c->slot[slot].T * K * 3 * sizeof(float2);
+        PSA_REQUIRE(out_bytes == bytes, "result is %zu bytes (T=%lld, K=%lld, complex64 x 3), the caller's buffer %zu", bytes,
+                    (long long)c->slot[slot].T, (long long)K, out_bytes);
+        const ProjectArgs a{slot, mean_pos_all, k_vectors, K, K, 0, group_idx, group_off, G, flags};
+        return calculate_pipelined(c, a, out_host);
+    }
     PSA_TRY(psa_sed_project(c, slot, mean_pos_all, k_vectors, K, K, 0, group_idx, group_off, G, flags));
     return psa_sed_finalize(c, out_host, out_bytes);
 }

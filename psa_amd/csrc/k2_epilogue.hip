@@ -17,7 +17,8 @@ constexpr int KT = 16;   // k-points per tile
 
 __global__ void __launch_bounds__(256)
 scale_transpose_c64_kernel(const float2* __restrict__ slab, float2* __restrict__ out, int64_t T,
-                           int64_t K) {
+                           int64_t K, int64_t K_pitch, int64_t k_first) {
+    // slab: rows of the K k-vectors [k_first, k_first + K) of a result with K_pitch k-vectors
     __shared__ float2 tile[KT * 3][TT + 1];
     const int64_t t0 = (int64_t)blockIdx.x * TT;
     const int64_t k0 = (int64_t)blockIdx.y * KT;
@@ -43,15 +44,16 @@ scale_transpose_c64_kernel(const float2* __restrict__ slab, float2* __restrict__
     const int kn = (int)((K - k0) < KT ? (K - k0) : KT) * 3;   // valid elements per frame row
     for (int item = tid; item < TT * KT * 3; item += 256) {
         const int tl = item / (KT * 3), e = item - tl * (KT * 3);
-        if (e < kn && t0 + tl < T) out[((t0 + tl) * K + k0) * 3 + e] = tile[e][tl];
+        if (e < kn && t0 + tl < T) out[((t0 + tl) * K_pitch + k_first + k0) * 3 + e] = tile[e][tl];
     }
 }
 
-int launch_scale_transpose_c64(psa_ctx* c, const float2* d_slab, float2* d_out, int64_t T, int64_t K) {
+int launch_scale_transpose_c64(psa_ctx* c, const float2* d_slab, float2* d_out, int64_t T, int64_t K, int64_t K_pitch,
+                               int64_t k_first) {
     const int64_t gy = (K + KT - 1) / KT;
     PSA_REQUIRE(gy <= 65535, "too many k-points for one transpose launch");
     dim3 grid((unsigned)((T + TT - 1) / TT), (unsigned)gy);
-    hipLaunchKernelGGL(scale_transpose_c64_kernel, grid, dim3(256), 0, c->stream, d_slab, d_out, T, K);
+    hipLaunchKernelGGL(scale_transpose_c64_kernel, grid, dim3(256), 0, c->stream, d_slab, d_out, T, K, K_pitch, k_first);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
 }

@@ -185,6 +185,8 @@ struct psa_ctx {
     uint64_t plane_tick = 0, plane_call_mark = 0;   // sets touched since the mark belong to the call in progress
     int64_t  opt_planes = 1, opt_planes_budget = 0, opt_planes_eager = 0, opt_planes_min_k = 17;
     psa::Stager stager;
+    hipStream_t d2h_stream = nullptr;         // result blocks leave while the next block is projected
+    hipEvent_t  d2h_ready = nullptr;
 
     // frame sharding (psa_sed_fs_*): geometry of the group in flight
     int64_t fs_T_total = 0, fs_T_local = 0, fs_K_total = 0, fs_rows_k0 = 0, fs_rows_nk = 0;
@@ -259,7 +261,9 @@ int    launch_k1_planes(psa_ctx* c, const void* d_planes, const void* d_phase, f
 
 // --- k2_epilogue.hip
 int launch_dft_bin(psa_ctx* c, const float2* d_q, int64_t T, int64_t bin, float2* d_out3);
-int launch_scale_transpose_c64(psa_ctx* c, const float2* d_slab, float2* d_out, int64_t T, int64_t K);
+// rows of k-vectors [k_first, k_first + K) of a K_pitch-vector result -> their columns of (T, K_pitch, 3)
+int launch_scale_transpose_c64(psa_ctx* c, const float2* d_slab_rows, float2* d_out, int64_t T, int64_t K, int64_t K_pitch,
+                               int64_t k_first);
 int launch_intensity_accumulate(psa_ctx* c, const float2* d_q, float* d_slab_rows, int64_t T,
                                 int64_t K_local, bool first_group);
 int launch_transpose_f32(psa_ctx* c, const float* d_slab, float* d_out, int64_t T, int64_t K);

@@ -87,6 +87,11 @@ class OracleEngine:
         if intensity:
             self._slab[rows] = acc.T
 
+    def calculate(self, slot, mean_pos_all, k_vectors, groups=None, flags=0):
+        self.project(slot, mean_pos_all, k_vectors, groups, flags)
+        T = self.slots[slot].shape[0]
+        return self.finalize(T, len(k_vectors), bool(flags & _hip.F_INTENSITY))
+
     def gather(self, root, k_offsets, k_counts):
         for r, eng in self._peers.items():
             if r == self.rank or k_counts[r] == 0:

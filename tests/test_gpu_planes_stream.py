@@ -402,3 +402,32 @@ def test_frame_sharded_single_rank_group(fresh_engine, trajs):
     group = dist.KShardGroup(eng, dist.Exchange(), mode="frames")
     calc = make_calculator(d).attach(shard_group=group)
     assert rel_max(calc.calculate(np.zeros(33, np.float32), kv).sed, ref) <= TOL
+
+
+# ------------------------------------------------------------------ result leaving block by block
+@pytest.mark.parametrize("n_k, idx, disp", [(200, None, False), (333, None, False), (192, [3, 9, 9, 60, 1, 17, 33, 2], False),
+                                            (260, None, True)])
+def test_long_complex_results_are_pipelined_and_equal_the_plain_path(fresh_engine, trajs, n_k, idx, disp):
+    """psa_sed_calculate produces a complex result of >= 192 k-vectors in blocks (project, FFT,
+    transpose, 2-D D2H on a copy stream while the next block is projected): same numbers as
+    project + finalize, and as the oracle."""
+    from psa_amd import _hip
+    eng = fresh_engine
+    d = trajs["a"]
+    src = d["positions"] if disp else d["velocities"]
+    slot, flags = (1, _hip.F_DISPLACEMENTS) if disp else (0, 0)
+    mean = O.mean_positions(d["positions"])
+    kv = _kvecs(n_k, seed=n_k)
+    groups = None if idx is None else [np.asarray(idx)]
+    eng.ensure_resident(slot, src)
+    for _ in range(2):                                            # on-the-fly kernels first, planes second
+        piped = eng.calculate(slot, mean, kv, groups, flags)
+        eng.project(slot, mean, kv, groups, flags)
+        plain = eng.finalize(src.shape[0], n_k, False)
+        assert piped.shape == plain.shape == (src.shape[0], n_k, 3)
+        assert rel_max(piped, plain) < 2e-6
+        # the result also stays on the device, whole
+        np.testing.assert_allclose(eng.result_intensity(src.shape[0], n_k), np.sum(np.abs(plain) ** 2, axis=-1), rtol=3e-6)
+    ref, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], d["dt_ps"], kv,
+                            basis_atom_indices=None if idx is None else list(idx), use_displacements=disp)
+    assert rel_max(piped, ref) <= TOL
