@@ -243,6 +243,9 @@ int psa_debug_plane_cache(psa_ctx* ctx, int64_t* n_sets, int64_t* bytes);
 int psa_comm_unique_id(void* out /* PSA_UNIQUE_ID_BYTES */);
 int psa_comm_init(psa_ctx* ctx, const void* unique_id, int rank, int nranks);
 int psa_comm_destroy(psa_ctx* ctx);
+/* every pair of ranks trades one small stamped block in the grouped point-to-point pattern the
+ * data path uses; PSA_ERCCL if anything arrives damaged.  Collective: all ranks call it. */
+int psa_comm_selftest(psa_ctx* ctx);
 int psa_sed_gather(psa_ctx* ctx, int root, const int64_t* k_offsets, const int64_t* k_counts);
 int psa_comm_barrier(psa_ctx* ctx);
 

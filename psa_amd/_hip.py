@@ -77,6 +77,7 @@ SIGNATURES = {
     "psa_comm_unique_id": (C.c_int, [C.c_void_p]),
     "psa_comm_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
     "psa_comm_destroy": (C.c_int, [_ctx]),
+    "psa_comm_selftest": (C.c_int, [_ctx]),
     "psa_sed_gather": (C.c_int, [_ctx, C.c_int, _i64p, _i64p]),
     "psa_comm_barrier": (C.c_int, [_ctx]),
     "psa_sed_fs_project": (C.c_int, [_ctx, C.c_int, _f32p, _f32p, C.c_int64, _i32p, C.c_int64, C.c_int32,
@@ -533,6 +534,9 @@ class Engine:
         buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
         _check(self._lib.psa_comm_init(self._h, buf, rank, nranks), "psa_comm_init")
         self.rank, self.nranks = rank, nranks
+
+    def comm_selftest(self):
+        _check(self._lib.psa_comm_selftest(self._h), "psa_comm_selftest")
 
     def comm_destroy(self):
         _check(self._lib.psa_comm_destroy(self._h), "psa_comm_destroy")

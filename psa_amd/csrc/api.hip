@@ -1687,6 +1687,45 @@ int psa_sed_fs_finish(psa_ctx* c, int32_t first_group) {
     return PSA_OK;
 }
 
+// One small grouped point-to-point round in the pattern psa_sed_gather / psa_sed_fs_exchange use
+// (every pair of ranks trades a stamped block), checked on arrival: run once after psa_comm_init so
+// that a communicator that formed but cannot move data is found before a calculation depends on it.
+int psa_comm_selftest(psa_ctx* c) {
+    PSA_TRY(enter(c));
+    Guard guard(c);
+    if (c->nranks == 1 || !c->comm) return PSA_OK;
+    const int           n = c->nranks, me = c->rank, words = 256;
+    std::vector<float>  out((size_t)n * words), in((size_t)n * words, -1.f);
+    for (int r = 0; r < n; ++r)
+        for (int i = 0; i < words; ++i) out[(size_t)r * words + i] = (float)(me * 1000 + r) + 0.001f * (float)i;
+    PSA_TRY(c->d_stage.reserve(2 * out.size() * sizeof(float)));
+    float* d_out = c->d_stage.as<float>();
+    float* d_in = d_out + out.size();
+    PSA_HIP_CHECK(hipMemcpyAsync(d_out, out.data(), out.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    PSA_HIP_CHECK(hipMemsetAsync(d_in, 0xff, in.size() * sizeof(float), c->stream));
+    PSA_NCCL_CHECK(ncclGroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int r = 0; r < n && bad == ncclSuccess; ++r) {
+        if (r == me) continue;
+        bad = ncclRecv(d_in + (size_t)r * words, words, ncclFloat, r, c->comm, c->stream);
+        if (bad == ncclSuccess) bad = ncclSend(d_out + (size_t)r * words, words, ncclFloat, r, c->comm, c->stream);
+    }
+    const ncclResult_t closed = ncclGroupEnd();
+    PSA_NCCL_CHECK(bad);
+    PSA_NCCL_CHECK(closed);
+    PSA_HIP_CHECK(hipMemcpyAsync(in.data(), d_in, in.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < n; ++r) {
+        if (r == me) continue;
+        for (int i = 0; i < words; ++i)
+            if (in[(size_t)r * words + i] != (float)(r * 1000 + me) + 0.001f * (float)i) {
+                set_error("RCCL self-test: block from rank %d arrived damaged (word %d)", r, i);
+                return PSA_ERCCL;
+            }
+    }
+    return PSA_OK;
+}
+
 int psa_comm_barrier(psa_ctx* c) {
     PSA_TRY(enter(c));
     Guard guard(c);

@@ -339,6 +339,16 @@ class KShardGroup:
                 err = str(e)
             # every rank must take the same path
             errors = [e for e in exchange.allgather(err) if e]
+            if not errors and hasattr(engine, "comm_selftest"):
+                # a communicator that formed must also move data: one small round in the data path's
+                # own pattern (every pair of ranks trades a stamped block), before anything depends on it
+                try:
+                    engine.comm_selftest()
+                except _hip.PsaHipError as e:
+                    err = str(e)
+                errors = [e for e in exchange.allgather(err) if e]
+                if errors:
+                    engine.comm_destroy()
             if errors:
                 self.transport = "host"
                 logger.warning("RCCL communicator could not be formed (%s); slab rows will be exchanged "

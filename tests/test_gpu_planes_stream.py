@@ -390,6 +390,7 @@ def test_frame_sharded_single_rank_group(fresh_engine, trajs):
     kv = _kvecs(33)
     eng.comm_init(eng.new_unique_id(), 0, 1)
     try:
+        eng.comm_selftest()
         eng.ensure_resident(0, vel)
         eng.fs_project(0, mean, kv, None, 0, vel.shape[0], 0, 33)
         eng.fs_exchange([0], [vel.shape[0]], [0], [33])
