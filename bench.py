@@ -116,19 +116,31 @@ def spawn_ranks(n: int, argv) -> int:
                    MASTER_PORT=str(port), PSA_BENCH_SPAWNED="1")
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    deadline = time.time() + 600
-    codes = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            codes.append(-9)
-    if any(codes):
+    import signal
+
+    def _stop(signum, _frame):                  # the launcher was told to stop: no rank outlives it
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        sys.exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, _stop)
+    signal.signal(signal.SIGINT, _stop)
+    # watch all ranks: the first one that fails takes the others down with it (a rank waiting in the
+    # rendezvous for a dead peer would otherwise sit there until its timeout)
+    deadline = time.time() + float(os.environ.get("PSA_BENCH_TIMEOUT_S", "3000"))
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs) or time.time() > deadline:
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.1)
+    out = procs[0].stdout.read()
+    codes = [p.wait() for p in procs]
+    if failed or any(codes):
         sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
         return 1
     lines = [ln for ln in out.decode().splitlines() if ln.strip()]

@@ -500,8 +500,9 @@ int staged_upload(psa_ctx* c, float* dev, const float* host, int64_t T, int64_t 
     size_t       target = (size_t)64 << 20;
     if (const char* e = std::getenv("PSA_UPLOAD_CHUNK_MIB")) target = (size_t)std::max(1, std::atoi(e)) << 20;
     int64_t frames = (int64_t)(target / row);
-    frames = std::max<int64_t>(64, frames / 64 * 64);          // whole projection tiles
-    frames = std::min(frames, T);
+    if (frames >= 64) frames = frames / 64 * 64;               // whole projection tiles
+    else if ((size_t)64 * row <= ((size_t)256 << 20)) frames = 64;
+    frames = std::min(std::max<int64_t>(frames, 1), T);        // (very wide rows: fewer frames per chunk)
     PSA_TRY(stager_init(c, (size_t)frames * row));
     Stager&                     st = c->stager;
     HostTimer                   ht(&c->oneoff_ms[3]);

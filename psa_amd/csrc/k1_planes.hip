@@ -87,6 +87,7 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
     const int     last = n_stage - 1;
     int           fg = tb * 4 + wf;                                  // frame group (past the end: the last one, never stored)
     if (fg >= n_fg) fg = n_fg - 1;
+    if constexpr ((PSA_K1P_X & 128) != 0) fg &= 63;   // experiment (WRONG results): every V read is an L2 / MALL hit
 
     // ---- DMA sources: this wavefront's blocks of the V planes and of the P' tile ----------------
     const unsigned char* vp = reinterpret_cast<const unsigned char*>(planes) +
