@@ -628,7 +628,7 @@ int psa_destroy(psa_ctx* c) {
         if (c->d2h_ready) (void)hipEventDestroy(c->d2h_ready);
         for (DevBuf* b : {&c->d_kvec, &c->d_mean_all, &c->d_idx, &c->d_mean_g, &c->d_phase, &c->d_qwork,
                           &c->d_fft_work, &c->d_tables, &c->d_absmax, &c->d_slab, &c->d_out, &c->d_aux, &c->d_sync,
-                          &c->d_qrows, &c->d_stage, &c->d_bin})
+                          &c->d_qrows, &c->d_stage, &c->d_bin, &c->d_upload_max})
             b->release();
         (void)hipStreamDestroy(c->stream);
     }
@@ -1005,6 +1005,15 @@ int psa_sed_project_upload(psa_ctx* c, int slot, const float* host, int64_t T, i
     int g0 = 0;                                                   // first non-empty group
     while (g0 < G && group_idx && group_off[g0 + 1] == group_off[g0]) ++g0;
     int rc = PSA_OK;
+    // the array's largest magnitude (scale of the f16 kernels on later calls) is folded chunk by chunk
+    // behind the copies too: no extra pass over the array after the upload
+    PSA_TRY(c->d_upload_max.reserve(sizeof(unsigned)));
+    PSA_HIP_CHECK(hipMemsetAsync(c->d_upload_max.ptr, 0, sizeof(unsigned), c->stream));
+    const size_t row_floats = (size_t)N * 3;
+    auto fold_max = [&](int64_t t0, int64_t nt) {
+        return launch_absmax_bits(c, c->slot[slot].buf.as<float>() + (size_t)t0 * row_floats, nt * (int64_t)row_floats,
+                                  c->d_upload_max.as<unsigned>(), false);
+    };
     if (g0 < G) {
         const int64_t  n_g = group_idx ? (group_off[g0 + 1] - group_off[g0]) : N;
         const int*     d_idx = group_idx ? c->d_idx.as<int>() + group_off[g0] : nullptr;
@@ -1017,12 +1026,17 @@ int psa_sed_project_upload(psa_ctx* c, int slot, const float* host, int64_t T, i
             rc = staged_upload(c, c->slot[slot].buf.as<float>(), host, T, N,
                                [&](int64_t t0, int64_t nt, hipEvent_t landed) -> int {
                                    PSA_HIP_CHECK(hipStreamWaitEvent(c->stream, landed, 0));
+                                   PSA_TRY(fold_max(t0, nt));
                                    return launch_projection(c, slot, d_idx, g, disp, nullptr, d_q, T, t0, nt);
                                });
         }
     } else {
         StageTimer st(c, PSA_T_H2D);
-        rc = staged_upload(c, c->slot[slot].buf.as<float>(), host, T, N, nullptr);
+        rc = staged_upload(c, c->slot[slot].buf.as<float>(), host, T, N,
+                           [&](int64_t t0, int64_t nt, hipEvent_t landed) -> int {
+                               PSA_HIP_CHECK(hipStreamWaitEvent(c->stream, landed, 0));
+                               return fold_max(t0, nt);
+                           });
     }
     planner.join();
     if (rc == PSA_OK && plan_rc != PSA_OK) {
@@ -1031,6 +1045,8 @@ int psa_sed_project_upload(psa_ctx* c, int slot, const float* host, int64_t T, i
     }
     PSA_TRY(rc);
     c->slot[slot].valid = true;
+    PSA_HIP_CHECK(hipMemcpyAsync(&c->slot[slot].absmax_bits, c->d_upload_max.ptr, sizeof(unsigned), hipMemcpyDeviceToHost,
+                                 c->stream));
     bool first = true;
     if (g0 < G) {
         {
@@ -1051,6 +1067,10 @@ int psa_sed_project_upload(psa_ctx* c, int slot, const float* host, int64_t T, i
         }
     }
     if (first) PSA_HIP_CHECK(hipMemsetAsync(rows, 0, row_bytes * (size_t)K, c->stream));
+    if (!c->slot[slot].absmax_known) {                           // (a later group's geometry may have asked already)
+        PSA_HIP_CHECK(hipStreamSynchronize(c->stream));            // the read-back above has landed
+        c->slot[slot].absmax_known = true;
+    }
     return PSA_OK;
 }
 

@@ -282,14 +282,39 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
 // floats go through LDS (coalesced reads along the row), then wavefront c converts component c,
 // each lane one 8-atom fragment, written as two 16-byte stores.
 // ---------------------------------------------------------------------------------------------
+// VEC: whole trajectory in its own order with N % 4 == 0 -- every 96-float row segment is 16-byte
+// aligned and is read as 24 float4 (two loads per thread instead of eight)
+template <bool VEC>
 __global__ void __launch_bounds__(192)
 split_planes_kernel(const float* __restrict__ x, const int* __restrict__ idx, _Float16* __restrict__ planes, int64_t T,
                     int64_t N_tot, int n_g, int n_stage, int64_t n_fg, float vscale) {
-    __shared__ float raw[16][100];
+    __shared__ __attribute__((aligned(16))) float raw[16][100];
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
     for (int64_t fg = blockIdx.y; fg < n_fg; fg += gridDim.y) {
         const int64_t t0 = fg * 16;
+        if constexpr (VEC) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int     e = tid + 192 * j;                 // float4 index in the 16 x 24 tile
+                const int     row = e / 24, c4 = e - row * 24;
+                const int64_t t = t0 + row;
+                f32x4         v = {0.f, 0.f, 0.f, 0.f};
+                // (atoms past n_g = N_tot: only the last stage can be short, and then by whole float4s
+                //  only if N % 32 is a multiple of 4/3 atoms -- handled per element below)
+                if (t < T) {
+                    const int64_t col = (int64_t)s * 96 + 4 * c4;
+                    if (col + 3 < 3 * N_tot) {
+                        v = *reinterpret_cast<const f32x4*>(x + t * 3 * N_tot + col);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (col + u < 3 * N_tot) v[u] = x[t * 3 * N_tot + col + u];
+                    }
+                }
+                *reinterpret_cast<f32x4*>(&raw[row][4 * c4]) = v;
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int     e = tid + 192 * j;
@@ -303,6 +328,7 @@ split_planes_kernel(const float* __restrict__ x, const int* __restrict__ idx, _F
                 v = x[(t * N_tot + atom) * 3 + comp];
             }
             raw[row][col] = v;
+        }
         }
         __syncthreads();
         const int comp = tid >> 6, r = (tid >> 2) & 15, oct = tid & 3;
@@ -324,8 +350,12 @@ int launch_split_planes(psa_ctx* c, const float* d_x, const int* d_idx, void* d_
     const int64_t n_fg = (T + 15) / 16;
     PSA_REQUIRE(n_stage > 0 && n_fg > 0 && vscale > 0.f, "bad split geometry");
     dim3 grid((unsigned)n_stage, (unsigned)(n_fg < 4096 ? n_fg : 4096));
-    hipLaunchKernelGGL(split_planes_kernel, grid, dim3(192), 0, c->stream, d_x, d_idx, (_Float16*)d_planes, T, N_tot, n_g,
-                       n_stage, n_fg, vscale);
+    if (d_idx == nullptr && n_g == N_tot && N_tot % 4 == 0)
+        hipLaunchKernelGGL(split_planes_kernel<true>, grid, dim3(192), 0, c->stream, d_x, d_idx, (_Float16*)d_planes, T, N_tot,
+                           n_g, n_stage, n_fg, vscale);
+    else
+        hipLaunchKernelGGL(split_planes_kernel<false>, grid, dim3(192), 0, c->stream, d_x, d_idx, (_Float16*)d_planes, T, N_tot,
+                           n_g, n_stage, n_fg, vscale);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
 }

@@ -227,8 +227,9 @@ int launch_absmax_blocks(psa_ctx* c, const float* d_x, int64_t T, int64_t N, uns
     return PSA_OK;
 }
 
-int launch_absmax_bits(psa_ctx* c, const float* d_x, int64_t n, unsigned* d_out) {
-    PSA_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(unsigned), c->stream));
+// reset = false: fold another piece of the array into a running maximum (chunks of an upload)
+int launch_absmax_bits(psa_ctx* c, const float* d_x, int64_t n, unsigned* d_out, bool reset) {
+    if (reset) PSA_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(unsigned), c->stream));
     const int64_t n4 = n / 4;
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;

@@ -177,6 +177,7 @@ struct psa_ctx {
 
     // per-call scratch
     psa::DevBuf d_kvec, d_mean_all, d_idx, d_mean_g, d_phase, d_qwork, d_fft_work, d_tables, d_absmax;
+    psa::DevBuf d_upload_max;                 // running largest magnitude of an array being uploaded
     psa::DevBuf d_qrows, d_stage, d_bin;      // frame sharding: my rows before the FFT / all-to-all landing zone; one DFT bin
 
     // cached split planes (PSA_OPT_PLANES*)
@@ -222,7 +223,7 @@ int launch_fill_synthetic(psa_ctx* c, float* d_v, int64_t T, int64_t N, uint64_t
                           const float* d_st, const float* d_ca, const float* d_sa);
 int launch_mean_over_frames(psa_ctx* c, const float* d_x, int64_t T, int64_t N, float* d_mean);
 int launch_subtract_mean(psa_ctx* c, const float* d_x, const float* d_mean, float* d_out, int64_t T, int64_t N);
-int launch_absmax_bits(psa_ctx* c, const float* d_x, int64_t n, unsigned* d_out);
+int launch_absmax_bits(psa_ctx* c, const float* d_x, int64_t n, unsigned* d_out, bool reset = true);
 int launch_absmax_blocks(psa_ctx* c, const float* d_x, int64_t T, int64_t N, unsigned* d_out);
 
 // --- k1_mfma.hip / k1_wave.hip
