@@ -19,7 +19,7 @@ groups=(
 )
 i=0
 for g in "${groups[@]}"; do
-  rocprofv3 --kernel-trace --pmc $g --output-format csv -d "$out/g$i" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$out/g$i.log" 2>&1 || echo "group $i failed (see $out/g$i.log)"
+  rocprofv3 --kernel-trace --pmc $g --output-format csv -d "$out/g$i" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > "$out/g$i.log" 2>&1 || echo "group $i failed (see $out/g$i.log)"
   i=$((i+1))
 done
 python3 "$ROOT/tools/pmc_summarise.py" "$out" > "$ROOT/gpurun_out/pmc_$tag.json"
