@@ -12,7 +12,8 @@ synthetic-trajectory generator used by the benchmark.  Loaders, plotting, CLI an
 reference are out of scope.
 """
 from .core import SED, SEDCalculator, Trajectory
+from .core.sed import fast_intensity
 from .utils.helpers import parse_direction
 
-__version__ = "0.1.0"
-__all__ = ["Trajectory", "SED", "SEDCalculator", "parse_direction", "__version__"]
+__version__ = "0.2.0"
+__all__ = ["Trajectory", "SED", "SEDCalculator", "parse_direction", "fast_intensity", "__version__"]

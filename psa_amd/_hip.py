@@ -243,6 +243,7 @@ class Engine:
         # race (the reference GUI computes on worker threads) hold this around the sequence.
         self.lock = threading.RLock()
         self.rank, self.nranks = 0, 1
+        self.result_serial = 0       # bumped by every call that replaces the result resident on the device
 
     # -- lifecycle -------------------------------------------------------------------
     def close(self):
@@ -277,7 +278,11 @@ class Engine:
         reading it.  Not a proof of equality -- `invalidate()` is the explicit way."""
         if a.size == 0:
             return 0
+        # an even sweep plus scattered positions (an even stride alone can sit on one column of a
+        # (T, N, 3) or (T, K, 3) array for ever); positions depend on the size only
         lin = np.arange(0, a.size, max(1, a.size // 4099), dtype=np.int64)[:4099]
+        if a.size > 8192:
+            lin = np.concatenate([lin, np.random.default_rng(a.size).integers(0, a.size, 4099), [a.size - 1]])
         return hash(a[np.unravel_index(lin, a.shape)].tobytes())     # a gather: never copies the array
 
     def _as_device_layout(self, slot: int, array: np.ndarray) -> np.ndarray:
@@ -384,6 +389,7 @@ class Engine:
         kv = _as_f32(k_vectors, (3,)) if len(k_vectors) else np.zeros((0, 3), np.float32)
         idx, off, G = pack_groups(groups)
         K_local = kv.shape[0]
+        self.result_serial += 1
         _check(self._lib.psa_sed_project(
             self._h, slot, _f32(mean), _f32(kv), K_local,
             K_local if K_total is None else K_total, k_offset,
@@ -399,6 +405,7 @@ class Engine:
         kv = _as_f32(k_vectors, (3,))
         idx, off, G = pack_groups(groups)
         self._resident.pop(slot, None)
+        self.result_serial += 1
         _check(self._lib.psa_sed_project_upload(
             self._h, slot, _f32(a), a.shape[0], a.shape[1], _f32(mean), _f32(kv), kv.shape[0],
             idx.ctypes.data_as(_i32p) if idx is not None else None,
@@ -436,6 +443,7 @@ class Engine:
         idx, off, G = pack_groups(groups)
         K = kv.shape[0]
         out = pinned_empty((T, K), np.float32) if flags & F_INTENSITY else pinned_empty((T, K, 3), np.complex64)
+        self.result_serial += 1
         _check(self._lib.psa_sed_calculate(
             self._h, slot, _f32(mean), _f32(kv), K,
             idx.ctypes.data_as(_i32p) if idx is not None else None,
@@ -450,8 +458,28 @@ class Engine:
 
     def slab_write(self, row0: int, rows: np.ndarray):
         rows = np.ascontiguousarray(rows)
+        self.result_serial += 1
         _check(self._lib.psa_slab_write(self._h, row0, rows.shape[0], rows.ctypes.data_as(C.c_void_p)),
                "psa_slab_write")
+
+    def intensity_source(self, array: np.ndarray):
+        """A callable for `SED._device_intensity`: given the array now in `SED.sed`, the intensity of
+        the complex result resident on the device -- or None if that is no longer this array's
+        result (another calculation came in between, the array was replaced or edited)."""
+        serial, ref, stamp = self.result_serial, weakref.ref(array), self._fingerprint(array)
+        T, K = array.shape[0], array.shape[1]
+
+        def source(current):
+            if current is not ref() or self._h is None:
+                return None
+            with self.lock:
+                if self.result_serial != serial or self._fingerprint(current) != stamp:
+                    return None
+                try:
+                    return self.result_intensity(T, K)
+                except PsaHipError:
+                    return None
+        return source
 
     def result_intensity(self, T: int, K: int) -> np.ndarray:
         out = pinned_empty((T, K), np.float32)
@@ -557,6 +585,7 @@ class Engine:
         mean = _as_f32(mean_pos_all, (3,))
         kv = _as_f32(k_vectors, (3,))
         ii = None if idx is None else np.ascontiguousarray(idx, np.int32)
+        self.result_serial += 1
         _check(self._lib.psa_sed_fs_project(
             self._h, slot, _f32(mean), _f32(kv), kv.shape[0], ii.ctypes.data_as(_i32p) if ii is not None else None,
             0 if ii is None else len(ii), flags, int(T_total), int(k_offset), int(k_count)), "psa_sed_fs_project")

@@ -17,6 +17,16 @@ import numpy as np
 
 logger = logging.getLogger(__name__)
 
+_FAST_INTENSITY = False
+
+
+def fast_intensity(enable: bool = True) -> None:
+    """Opt in to (or out of) serving `SED.intensity` from the result still resident on the GPU
+    (see the property's docstring for the one caveat)."""
+    global _FAST_INTENSITY
+    _FAST_INTENSITY = bool(enable)
+
+
 _REQUIRED = ("sed", "freqs", "k_points", "k_vectors")
 _OPTIONAL = ("k_grid_shape", "phase")
 
@@ -33,8 +43,26 @@ class SED:
 
     @property
     def intensity(self) -> np.ndarray:
-        """sum over the last axis of |sed|^2 as float32 (reference sed.py:22-24)."""
+        """sum over the last axis of |sed|^2 as float32 (reference sed.py:22-24) -- by default exactly
+        the reference's NumPy expression on whatever `self.sed` holds now.
+
+        With `psa_amd.fast_intensity(True)` (off by default) a complex result that
+        `SEDCalculator.calculate` has just produced is summed on the GPU, where it is still resident
+        (`psa_result_intensity`: ~1 ms instead of the tens of ms NumPy needs at configuration sizes),
+        provided no later calculation ran on that engine and `self.sed` is still the array that was
+        returned.  "Still" is checked on ~8000 sampled elements, not on all of them: an in-place edit
+        of a few elements can go unnoticed -- that is why it is opt-in."""
+        source = getattr(self, "_device_intensity", None) if _FAST_INTENSITY else None
+        if source is not None:
+            fast = source(self.sed)
+            if fast is not None:
+                return fast
         return np.sum(np.abs(self.sed) ** 2, axis=-1).astype(np.float32)
+
+    def __getstate__(self):                            # the device hook does not travel (pickle, deepcopy)
+        state = dict(self.__dict__)
+        state.pop("_device_intensity", None)
+        return state
 
     @staticmethod
     def _file(base_path: Path, field: str) -> Path:

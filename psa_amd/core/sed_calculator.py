@@ -330,8 +330,13 @@ class SEDCalculator:
         else:
             data = self._run_device(np.asarray(k_vectors_3d), self._device_groups(groups), True,
                                     mean_pos_all)
-        return SED(data, freqs, k_points_mags, k_vectors_3d, k_grid_shape=k_grid_shape,
-                   is_complex=is_complex, phase=None)
+        sed = SED(data, freqs, k_points_mags, k_vectors_3d, k_grid_shape=k_grid_shape,
+                  is_complex=is_complex, phase=None)
+        if (is_complex and n_k and isinstance(data, np.ndarray) and data.ndim == 3
+                and self._shard is None and hasattr(self._engine, "intensity_source")):
+            # `sed.intensity` right after the calculation is served from the result still on the device
+            sed._device_intensity = self._engine.intensity_source(data)
+        return sed
 
     # ------------------------------------------------------------------ chiral phase
     def calculate_chiral_phase(self, Z1: np.ndarray, Z2: np.ndarray, angle_range_opt: str = "C") -> np.ndarray:

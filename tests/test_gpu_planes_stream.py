@@ -432,3 +432,36 @@ def test_long_complex_results_are_pipelined_and_equal_the_plain_path(fresh_engin
     ref, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], d["dt_ps"], kv,
                             basis_atom_indices=None if idx is None else list(idx), use_displacements=disp)
     assert rel_max(piped, ref) <= TOL
+
+
+def test_intensity_from_the_resident_result_is_opt_in_and_guarded(fresh_engine, trajs):
+    """`SED.intensity` is the reference's NumPy expression unless psa_amd.fast_intensity(True); then
+    it is served from the result on the device while that result is still this SED's, and falls
+    back to NumPy as soon as another calculation ran or the array was edited."""
+    import copy
+    import pickle
+    import psa_amd
+    eng = fresh_engine
+    calc = make_calculator(trajs["a"]).attach(engine=eng)
+    mags, vecs = calc.get_k_path("100", 1.0, 24)
+    sed = calc.calculate(mags, vecs)
+    want = np.sum(np.abs(sed.sed) ** 2, axis=-1).astype(np.float32)
+    np.testing.assert_array_equal(sed.intensity, want)                       # default: NumPy, bit for bit
+    psa_amd.fast_intensity(True)
+    try:
+        eng.timings()
+        fast = sed.intensity
+        assert eng.timings()["epilogue"] > 0                                  # the device kernel ran
+        np.testing.assert_allclose(fast, want, rtol=3e-6)
+        assert pickle.loads(pickle.dumps(sed)).intensity.shape == want.shape and copy.deepcopy(sed) is not None
+        other = calc.calculate(mags, vecs[:20])                               # another result on the engine
+        eng.timings()
+        np.testing.assert_array_equal(sed.intensity, want)                    # stale hook -> NumPy
+        assert eng.timings()["epilogue"] == 0
+        np.testing.assert_allclose(other.intensity, np.sum(np.abs(other.sed) ** 2, axis=-1), rtol=3e-6)
+        other.sed[:] *= 2                                                     # edited in place -> NumPy again
+        eng.timings()
+        np.testing.assert_array_equal(other.intensity, np.sum(np.abs(other.sed) ** 2, axis=-1).astype(np.float32))
+        assert eng.timings()["epilogue"] == 0
+    finally:
+        psa_amd.fast_intensity(False)
