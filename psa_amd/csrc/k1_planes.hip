@@ -29,6 +29,10 @@
 //      instruction offset (it moves the global AND the LDS address: tools/probes/dma_offset.hip) --
 //      one M0 write per group and no 64-bit VALU address arithmetic
 //  64: main loop unrolled over the slot ring (LDS addresses become instruction offsets)
+// Tried and removed (configuration 3, same box, 14.9 ms shipped): A fragments double-buffered with all
+// 14 LDS reads of the next stage at the top of the stage 16.4 ms (an in-order wavefront cannot issue
+// its MFMAs behind a read burst that fills the LDS queue); the same with the reads paced one per two
+// MFMAs (sched_group_barrier) 14.9 ms -- no schedule moves the launch any more: it is power-limited.
 #ifndef PSA_K1P_X
 #define PSA_K1P_X 51        // product build: 1 + 2 + 16 + 32 (64 measured 3 % slower)
 #endif
