@@ -100,10 +100,21 @@ def parse_args(argv=None):
 
 # --------------------------------------------------------------------------- self-launch
 def _free_port():
+    """A port p with p + 17 free as well (the ranks' TCP rendezvous listens on MASTER_PORT + 17)."""
     import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    for _ in range(64):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            p = s.getsockname()[1]
+        if p + 17 > 65535:
+            continue
+        try:
+            with socket.socket() as s2:
+                s2.bind(("127.0.0.1", p + 17))
+            return p
+        except OSError:
+            continue
+    return 29500
 
 
 def spawn_ranks(n: int, argv) -> int:

@@ -14,7 +14,7 @@ ROOT = Path(__file__).resolve().parent.parent
 tag = sys.argv[1]
 out, scratch = ROOT / "profiles", ROOT / "gpurun_out"
 
-stats = sorted((scratch / f"prof_{tag}").rglob("*kernel_stats.csv"))
+stats = sorted((scratch / f"prof_{tag}").rglob("*kernel_stats.csv"), key=lambda p: p.stat().st_mtime)
 if stats:
     shutil.copy(stats[-1], out / f"{tag}_C3_kernel_stats.csv")
     shutil.copy(scratch / f"prof_{tag}_bench.json", out / f"{tag}_C3_bench.json")
