@@ -1002,6 +1002,12 @@ int psa_sed_project_upload(psa_ctx* c, int slot, const float* host, int64_t T, i
         plan_rc = get_plan(c, T, 3 * K, &p);
         if (plan_rc != PSA_OK) plan_err = g_error;
     });
+    struct JoinOnExit {                                           // no path leaves with the thread running
+        std::thread& t;
+        ~JoinOnExit() {
+            if (t.joinable()) t.join();
+        }
+    } join_planner{planner};
     int g0 = 0;                                                   // first non-empty group
     while (g0 < G && group_idx && group_off[g0 + 1] == group_off[g0]) ++g0;
     int rc = PSA_OK;
