@@ -278,6 +278,18 @@ class Engine:
         reading it.  Not a proof of equality -- `invalidate()` is the explicit way."""
         if a.size == 0:
             return 0
+        # a memory-mapped file (the reference's .npy cache, io/loader.py:48-79) is not sampled --
+        # scattered reads of a file that may not sit in the page cache cost a disk seek each --
+        # but identified by the file's name, size and modification time
+        base = a
+        while base is not None and not isinstance(base, np.memmap):
+            base = getattr(base, "base", None)
+        if base is not None and getattr(base, "filename", None):
+            try:
+                st = os.stat(base.filename)
+                return hash((str(base.filename), st.st_size, st.st_mtime_ns, a.shape, a.strides))
+            except OSError:
+                pass
         # an even sweep plus scattered positions (an even stride alone can sit on one column of a
         # (T, N, 3) or (T, K, 3) array for ever); positions depend on the size only
         lin = np.arange(0, a.size, max(1, a.size // 4099), dtype=np.int64)[:4099]

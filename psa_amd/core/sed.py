@@ -46,7 +46,7 @@ class SED:
         """sum over the last axis of |sed|^2 as float32 (reference sed.py:22-24) -- by default exactly
         the reference's NumPy expression on whatever `self.sed` holds now.
 
-        With `psa_amd.fast_intensity(True)` (off by default) a complex result that
+        With `psa_amd.fast_intensity(True)` (off by default; switch it on before the calculation) a complex result that
         `SEDCalculator.calculate` has just produced is summed on the GPU, where it is still resident
         (`psa_result_intensity`: ~1 ms instead of the tens of ms NumPy needs at configuration sizes),
         provided no later calculation ran on that engine and `self.sed` is still the array that was

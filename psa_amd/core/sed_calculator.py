@@ -332,7 +332,8 @@ class SEDCalculator:
                                     mean_pos_all)
         sed = SED(data, freqs, k_points_mags, k_vectors_3d, k_grid_shape=k_grid_shape,
                   is_complex=is_complex, phase=None)
-        if (is_complex and n_k and isinstance(data, np.ndarray) and data.ndim == 3
+        from . import sed as _sed_module
+        if (_sed_module._FAST_INTENSITY and is_complex and n_k and isinstance(data, np.ndarray) and data.ndim == 3
                 and self._shard is None and hasattr(self._engine, "intensity_source")):
             # `sed.intensity` right after the calculation is served from the result still on the device
             sed._device_intensity = self._engine.intensity_source(data)
