@@ -918,9 +918,21 @@ int project_groups(psa_ctx* c, const ProjectArgs& a, int slot, bool disp, int g_
         const int32_t* h_idx = a.group_idx ? a.group_idx + a.group_off[gi] : nullptr;
         PlaneSet*      ps = nullptr;
         if (!disp) PSA_TRY(get_planes(c, slot, d_idx, h_idx, n_g, a.K_local, &ps));
-        ProjGeom g;
-        PSA_TRY(make_geom(c, slot, a.K_local, n_g, d_idx, h_idx, disp, ps, 0, &g));
-        PSA_TRY(project_group(c, slot, d_idx, g, disp, ps, d_q));
+        // the phase table holds 8 bytes per (k-vector, atom): very long k-lists (a 500 x 500 grid) are
+        // projected in blocks whose table stays under 2 GiB (the reference chunks k for the same reason,
+        // sed_calculator.py:268-272); ordinary lists are one block
+        const int64_t per_k = 8 * ((n_g + 63) / 64 * 64);
+        int64_t       table = (int64_t)2 << 30;
+        if (const char* e = std::getenv("PSA_PHASE_TABLE_MIB")) table = (int64_t)std::max(1, std::atoi(e)) << 20;
+        int64_t kb = std::max<int64_t>(64, (table / per_k) / 64 * 64);
+        if (a.K_local <= kb + 64) kb = a.K_local;
+        for (int64_t k0 = 0; k0 < a.K_local; k0 += kb) {
+            const int64_t nk = std::min(kb, a.K_local - k0);
+            ProjGeom      g;
+            PSA_TRY(make_geom(c, slot, nk, n_g, d_idx, h_idx, disp, ps, 0, &g));
+            PSA_TRY(prepare_phase(c, d_idx, g, disp, k0));
+            PSA_TRY(launch_projection(c, slot, d_idx, g, disp, ps, d_q + (size_t)k0 * 3 * (size_t)T, T, 0, T));
+        }
         {
             StageTimer st(c, PSA_T_FFT);
             PSA_TRY(run_fft(c, d_q, T, 3 * a.K_local));

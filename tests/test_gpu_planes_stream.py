@@ -469,3 +469,26 @@ def test_intensity_from_the_resident_result_is_opt_in_and_guarded(fresh_engine, 
         assert eng.timings()["epilogue"] == 0
     finally:
         psa_amd.fast_intensity(False)
+
+
+def test_very_long_k_lists_are_projected_in_blocks(fresh_engine, monkeypatch):
+    """The phase table (8 bytes per k-vector and atom) is bounded: a k-list whose table would exceed
+    the limit (2 GiB; 1 MiB here) is projected in blocks of k-vectors -- same result."""
+    from psa_amd import _hip
+    eng = fresh_engine
+    pos, vel = _random_traj(1000, 96, seed=6)
+    mean, kv = O.mean_positions(pos), _kvecs(300, seed=2)
+    types = np.where(np.arange(1000) < 400, 1, 2)
+    eng.ensure_resident(0, vel)
+    eng.project(0, mean, kv)
+    whole = eng.finalize(96, 300, False)
+    groups = [np.flatnonzero(types == 1), np.flatnonzero(types == 2)]
+    eng.project(0, mean, kv, groups, _hip.F_INTENSITY)
+    whole_inc = eng.finalize(96, 300, True)
+    monkeypatch.setenv("PSA_PHASE_TABLE_MIB", "1")               # 1024 atoms x 8 B -> blocks of 128 k-vectors
+    eng.project(0, mean, kv)
+    np.testing.assert_array_equal(eng.finalize(96, 300, False), whole)       # same kernels per k-vector
+    eng.project(0, mean, kv, groups, _hip.F_INTENSITY)
+    np.testing.assert_allclose(eng.finalize(96, 300, True), whole_inc, rtol=1e-6)
+    ref, _, _ = O.calculate(pos, vel, types, 0.002, kv)
+    assert rel_max(whole, ref) <= TOL
