@@ -50,3 +50,23 @@ def test_bench_runs_as_one_rank_under_a_launcher():
 def test_a_failing_rank_fails_the_launch():
     res = _run("--gpus", "2", "--config", "C9")            # argparse rejects it in every rank
     assert res.returncode != 0 and not res.stdout.strip()
+
+
+def test_bench_under_torch_distributed_run():
+    """The launch line the driver uses for N > 1: torch.distributed.run exports RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*, bench.py runs as one of its ranks (it does not import torch itself)."""
+    pytest.importorskip("torch")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--stub-engine", "--config", "C1",
+           "--steps", "2", "--warmup", "1"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["k_points_per_rank"] == [16, 16]
