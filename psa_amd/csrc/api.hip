@@ -172,7 +172,7 @@ int group_absmax(psa_ctx* c, int slot, const int32_t* h_idx, int64_t n_g, unsign
         HostTimer    ht(&c->oneoff_ms[1]);
         const size_t n_blocks = (size_t)((s.N + 31) / 32);
         PSA_TRY(c->d_absmax.reserve(n_blocks * sizeof(unsigned)));
-        PSA_TRY(launch_absmax_blocks(c, s.buf.as<float>(), s.T, s.N, c->d_absmax.as<unsigned>()));
+        PSA_TRY(launch_absmax_blocks(c, s.buf.as<float>(), nullptr, s.T, s.N, c->d_absmax.as<unsigned>()));
         s.block_absmax.resize(n_blocks);
         PSA_HIP_CHECK(hipMemcpyAsync(s.block_absmax.data(), c->d_absmax.ptr, n_blocks * sizeof(unsigned),
                                      hipMemcpyDeviceToHost, c->stream));
@@ -181,6 +181,34 @@ int group_absmax(psa_ctx* c, int slot, const int32_t* h_idx, int64_t n_g, unsign
     }
     unsigned m = 0;
     for (int64_t i = 0; i < n_g; ++i) m = std::max(m, s.block_absmax[(size_t)h_idx[i] >> 5]);
+    *bits = m;
+    return PSA_OK;
+}
+
+// the same for slot - mean (displacement mode; the mean is in d_mean_all): per-block table cached for
+// (slot contents, mean); h_idx null = all atoms
+int displaced_absmax(psa_ctx* c, int slot, const float* mean_host, const int32_t* h_idx, int64_t n_g, unsigned* bits) {
+    DataSlot&    s = c->slot[slot];
+    const size_t n_mean = (size_t)s.N * 3, n_blocks = (size_t)((s.N + 31) / 32);
+    const bool   fresh = c->disp_abs_source == s.generation && c->disp_abs_mean.size() == n_mean &&
+                       c->disp_block_absmax.size() == n_blocks &&
+                       std::memcmp(c->disp_abs_mean.data(), mean_host, n_mean * sizeof(float)) == 0;
+    if (!fresh) {
+        HostTimer ht(&c->oneoff_ms[1]);
+        PSA_TRY(c->d_absmax.reserve(n_blocks * sizeof(unsigned)));
+        PSA_TRY(launch_absmax_blocks(c, s.buf.as<float>(), c->d_mean_all.as<float>(), s.T, s.N, c->d_absmax.as<unsigned>()));
+        c->disp_block_absmax.resize(n_blocks);
+        PSA_HIP_CHECK(hipMemcpyAsync(c->disp_block_absmax.data(), c->d_absmax.ptr, n_blocks * sizeof(unsigned),
+                                     hipMemcpyDeviceToHost, c->stream));
+        PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->disp_abs_mean.assign(mean_host, mean_host + n_mean);
+        c->disp_abs_source = s.generation;
+    }
+    unsigned m = 0;
+    if (h_idx)
+        for (int64_t i = 0; i < n_g; ++i) m = std::max(m, c->disp_block_absmax[(size_t)h_idx[i] >> 5]);
+    else
+        for (unsigned b : c->disp_block_absmax) m = std::max(m, b);
     *bits = m;
     return PSA_OK;
 }
@@ -227,17 +255,20 @@ bool evict_one_plane_set(psa_ctx* c) {
 // (PSA_OPT_PLANES*) and HBM allow; *out stays nullptr otherwise and the caller projects with the
 // kernels that split on the fly.  h_idx / d_idx: the group's index list on the host / device
 // (nullptr: all atoms in order).
+// mean_host non-null: planes of slot - mean (displacement mode; the mean is also in d_mean_all).
 int get_planes(psa_ctx* c, int slot, const int* d_idx, const int32_t* h_idx, int64_t n_g, int64_t K_local,
-               PlaneSet** out) {
+               const float* mean_host, PlaneSet** out) {
     *out = nullptr;
     if (c->k1_selector != PSA_K1_AUTO || !c->opt_planes || K_local < c->opt_planes_min_k) return PSA_OK;
     DataSlot& s = c->slot[slot];
     drop_stale_planes(c);
-    const bool     all = h_idx == nullptr;
-    const uint64_t h = all ? 0 : hash_idx(h_idx, n_g);
+    const bool     all = h_idx == nullptr, displaced = mean_host != nullptr;
+    const uint64_t h = (all ? 0 : hash_idx(h_idx, n_g)) ^ (displaced ? 0x9E3779B97F4A7C15ull : 0);
+    const size_t   n_mean = (size_t)s.N * 3;
     for (auto& ps : c->planes)
-        if (ps->slot == slot && ps->all_atoms == all && ps->n_g == n_g &&
-            (all || (ps->idx_hash == h && std::memcmp(ps->idx.data(), h_idx, (size_t)n_g * sizeof(int32_t)) == 0))) {
+        if (ps->slot == slot && ps->all_atoms == all && ps->n_g == n_g && ps->displaced == displaced &&
+            (all || (ps->idx_hash == h && std::memcmp(ps->idx.data(), h_idx, (size_t)n_g * sizeof(int32_t)) == 0)) &&
+            (!displaced || (ps->mean.size() == n_mean && std::memcmp(ps->mean.data(), mean_host, n_mean * sizeof(float)) == 0))) {
             ps->last_use = ++c->plane_tick;
             *out = ps.get();
             return PSA_OK;
@@ -251,7 +282,9 @@ int get_planes(psa_ctx* c, int slot, const int* d_idx, const int32_t* h_idx, int
         }
     }
     unsigned bits = 0;
-    if (all) {
+    if (displaced) {
+        PSA_TRY(displaced_absmax(c, slot, mean_host, h_idx, n_g, &bits));
+    } else if (all) {
         PSA_TRY(slot_absmax(c, slot));
         bits = s.absmax_bits;
     } else {
@@ -281,7 +314,8 @@ int get_planes(psa_ctx* c, int slot, const int* d_idx, const int32_t* h_idx, int
     {
         HostTimer ht(&c->oneoff_ms[2]);                 // timed: the stream is drained once per set
         PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
-        PSA_TRY(launch_split_planes(c, s.buf.as<float>(), d_idx, ps->buf.ptr, s.T, s.N, (int)n_g, A_pad, vscale));
+        PSA_TRY(launch_split_planes(c, s.buf.as<float>(), displaced ? c->d_mean_all.as<float>() : nullptr, d_idx, ps->buf.ptr,
+                                    s.T, s.N, (int)n_g, A_pad, vscale));
         PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     ps->slot = slot;
@@ -289,6 +323,8 @@ int get_planes(psa_ctx* c, int slot, const int* d_idx, const int32_t* h_idx, int
     ps->all_atoms = all;
     if (!all) ps->idx.assign(h_idx, h_idx + n_g);
     ps->idx_hash = h;
+    ps->displaced = displaced;
+    if (displaced) ps->mean.assign(mean_host, mean_host + n_mean);
     ps->T = s.T;
     ps->n_fg = n_fg;
     ps->n_g = (int)n_g;
@@ -859,6 +895,23 @@ int materialise_displacements(psa_ctx* c, int* slot_io, bool* disp, const float*
     return PSA_OK;
 }
 
+// Where one group's data comes from.  In order: its cached split planes -- of the velocities, or of
+// positions - mean built straight from the positions (no float32 displacement array) -- else the
+// float32 slot, which in displacement mode is the materialised positions - mean array (or, when HBM
+// has no room for it, the positions themselves with the subtract-while-staging kernel).
+// *slot_io / *disp_io come in as the caller's slot and PSA_F_DISPLACEMENTS and go out as what the
+// projection has to be launched with.
+static int group_source(psa_ctx* c, int* slot_io, bool* disp_io, const float* mean_host, const int* d_idx,
+                        const int32_t* h_idx, int64_t n_g, int64_t K, PlaneSet** ps) {
+    *ps = nullptr;
+    PSA_TRY(get_planes(c, *slot_io, d_idx, h_idx, n_g, K, *disp_io ? mean_host : nullptr, ps));
+    if (*ps) {
+        *disp_io = false;                                         // the planes already hold slot - mean
+        return PSA_OK;
+    }
+    return materialise_displacements(c, slot_io, disp_io, mean_host);
+}
+
 // ---- the hot path ---------------------------------------------------------------
 namespace {
 
@@ -907,9 +960,9 @@ int upload_project_inputs(psa_ctx* c, const ProjectArgs& a, int64_t N) {
 }
 
 // groups [g_first, G) on the resident slot: project, FFT, epilogue
-int project_groups(psa_ctx* c, const ProjectArgs& a, int slot, bool disp, int g_first, bool* first, char* rows,
+int project_groups(psa_ctx* c, const ProjectArgs& a, int slot_in, bool disp_in, int g_first, bool* first, char* rows,
                    float2* d_q) {
-    const int64_t T = c->slot[slot].T, N = c->slot[slot].N;
+    const int64_t T = c->slot[slot_in].T, N = c->slot[slot_in].N;
     const bool    intensity = (a.flags & PSA_F_INTENSITY) != 0;
     for (int gi = g_first; gi < a.G; ++gi) {
         const int64_t n_g = a.group_idx ? (a.group_off[gi + 1] - a.group_off[gi]) : N;
@@ -917,7 +970,9 @@ int project_groups(psa_ctx* c, const ProjectArgs& a, int slot, bool disp, int g_
         const int*     d_idx = a.group_idx ? c->d_idx.as<int>() + a.group_off[gi] : nullptr;
         const int32_t* h_idx = a.group_idx ? a.group_idx + a.group_off[gi] : nullptr;
         PlaneSet*      ps = nullptr;
-        if (!disp) PSA_TRY(get_planes(c, slot, d_idx, h_idx, n_g, a.K_local, &ps));
+        int            slot = slot_in;
+        bool           disp = disp_in;
+        PSA_TRY(group_source(c, &slot, &disp, a.mean_pos_all, d_idx, h_idx, n_g, a.K_local, &ps));
         // the phase table holds 8 bytes per (k-vector, atom): very long k-lists (a 500 x 500 grid) are
         // projected in blocks whose table stays under 2 GiB (the reference chunks k for the same reason,
         // sed_calculator.py:268-272); ordinary lists are one block
@@ -964,7 +1019,6 @@ int psa_sed_project(psa_ctx* c, int slot, const float* mean_pos_all, const float
     PSA_TRY(begin_result(c, T, K_total, k_offset, intensity, &rows, &row_bytes));
     if (K_local == 0) return PSA_OK;
     PSA_TRY(upload_project_inputs(c, a, N));
-    PSA_TRY(materialise_displacements(c, &slot, &disp, mean_pos_all));
 
     float2* d_q = intensity ? nullptr : (float2*)rows;
     if (intensity) {
@@ -1077,12 +1131,7 @@ int psa_sed_project_upload(psa_ctx* c, int slot, const float* host, int64_t T, i
         }
         first = false;
         // remaining groups on the now resident array, by the ordinary rule
-        int  slot2 = slot;
-        bool disp2 = disp;
-        if (g0 + 1 < G) {
-            PSA_TRY(materialise_displacements(c, &slot2, &disp2, mean_pos_all));
-            PSA_TRY(project_groups(c, a, slot2, disp2, g0 + 1, &first, rows, d_q));
-        }
+        if (g0 + 1 < G) PSA_TRY(project_groups(c, a, slot, disp, g0 + 1, &first, rows, d_q));
     }
     if (first) PSA_HIP_CHECK(hipMemsetAsync(rows, 0, row_bytes * (size_t)K, c->stream));
     if (!c->slot[slot].absmax_known) {                           // (a later group's geometry may have asked already)
@@ -1165,7 +1214,6 @@ static int calculate_pipelined(psa_ctx* c, const ProjectArgs& a, void* out_host)
     size_t row_bytes = 0;
     PSA_TRY(begin_result(c, T, K, 0, false, &rows, &row_bytes));
     PSA_TRY(upload_project_inputs(c, a, N));
-    PSA_TRY(materialise_displacements(c, &slot, &disp, a.mean_pos_all));
     PSA_TRY(c->d_out.reserve(result_bytes(c)));
     if (!c->d2h_stream) PSA_HIP_CHECK(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
     if (!c->d2h_ready) PSA_HIP_CHECK(hipEventCreateWithFlags(&c->d2h_ready, hipEventDisableTiming));
@@ -1180,7 +1228,7 @@ static int calculate_pipelined(psa_ctx* c, const ProjectArgs& a, void* out_host)
         return PSA_OK;
     }
     PlaneSet* ps = nullptr;
-    if (!disp) PSA_TRY(get_planes(c, slot, d_idx, h_idx, n_g, K, &ps));
+    PSA_TRY(group_source(c, &slot, &disp, a.mean_pos_all, d_idx, h_idx, n_g, K, &ps));
     const size_t pitch = (size_t)K * 3 * sizeof(float2);
     int64_t      k0 = 0;
     for (const int64_t nk : pipeline_blocks(K, n_g)) {
@@ -1252,11 +1300,10 @@ int psa_sed_single_bin(psa_ctx* c, int slot, const float* mean_pos_all, const fl
     PSA_TRY(upload(c, c->d_kvec, k_vector, 3 * sizeof(float)));
     PSA_TRY(upload(c, c->d_mean_all, mean_pos_all, (size_t)N * 3 * sizeof(float)));
     if (idx) PSA_TRY(upload(c, c->d_idx, idx, (size_t)n_g * sizeof(int32_t)));
-    PSA_TRY(materialise_displacements(c, &slot, &disp, mean_pos_all));
     const int* d_idx = idx ? c->d_idx.as<int>() : nullptr;
     c->plane_call_mark = c->plane_tick + 1;
     PlaneSet* ps = nullptr;
-    if (!disp) PSA_TRY(get_planes(c, slot, d_idx, idx, n_g, 1, &ps));
+    PSA_TRY(group_source(c, &slot, &disp, mean_pos_all, d_idx, idx, n_g, 1, &ps));
     ProjGeom g;
     PSA_TRY(make_geom(c, slot, 1, n_g, d_idx, idx, disp, ps, 0, &g));
     PSA_TRY(c->d_qwork.reserve((size_t)3 * T * sizeof(float2)));
@@ -1448,11 +1495,10 @@ static int debug_project(psa_ctx* c, int slot, const float* mean_pos_all, const 
     if (idx) PSA_TRY(upload(c, c->d_idx, idx, (size_t)n_g * sizeof(int32_t)));
     ProjGeom g;
     bool disp = (flags & PSA_F_DISPLACEMENTS) != 0;
-    PSA_TRY(materialise_displacements(c, &slot, &disp, mean_pos_all));
     const int* d_idx = idx ? c->d_idx.as<int>() : nullptr;
     c->plane_call_mark = c->plane_tick + 1;
     PlaneSet* ps = nullptr;
-    if (!disp) PSA_TRY(get_planes(c, slot, d_idx, idx, n_g, K, &ps));
+    PSA_TRY(group_source(c, &slot, &disp, mean_pos_all, d_idx, idx, n_g, K, &ps));
     PSA_TRY(make_geom(c, slot, K, n_g, d_idx, idx, disp, ps, 0, &g));
     const size_t bytes = (size_t)K * 3 * T * sizeof(float2);
     PSA_TRY(c->d_qwork.reserve(bytes));
@@ -1627,10 +1673,9 @@ int psa_sed_fs_project(psa_ctx* c, int slot, const float* mean_pos_all, const fl
     PSA_TRY(upload(c, c->d_kvec, k_vectors, (size_t)K_total * 3 * sizeof(float)));
     PSA_TRY(upload(c, c->d_mean_all, mean_pos_all, (size_t)N * 3 * sizeof(float)));
     if (idx) PSA_TRY(upload(c, c->d_idx, idx, (size_t)n_g * sizeof(int32_t)));
-    PSA_TRY(materialise_displacements(c, &slot, &disp, mean_pos_all));
     const int* d_idx = idx ? c->d_idx.as<int>() : nullptr;
     PlaneSet*  ps = nullptr;
-    if (!disp) PSA_TRY(get_planes(c, slot, d_idx, idx, n_g, K_total, &ps));
+    PSA_TRY(group_source(c, &slot, &disp, mean_pos_all, d_idx, idx, n_g, K_total, &ps));
     ProjGeom g;
     PSA_TRY(make_geom(c, slot, K_total, n_g, d_idx, idx, disp, ps, 0, &g));
     return project_group(c, slot, d_idx, g, disp, ps, c->d_qwork.as<float2>());

@@ -290,8 +290,10 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
 // aligned and is read as 24 float4 (two loads per thread instead of eight)
 template <bool VEC>
 __global__ void __launch_bounds__(192)
-split_planes_kernel(const float* __restrict__ x, const int* __restrict__ idx, _Float16* __restrict__ planes, int64_t T,
-                    int64_t N_tot, int n_g, int n_stage, int64_t n_fg, float vscale) {
+split_planes_kernel(const float* __restrict__ x, const float* __restrict__ mean, const int* __restrict__ idx,
+                    _Float16* __restrict__ planes, int64_t T, int64_t N_tot, int n_g, int n_stage, int64_t n_fg, float vscale) {
+    // mean (N_tot,3), may be null: the planes hold x - mean, one float32 subtraction per element like
+    // the reference's temporary (sed_calculator.py:70-72)
     __shared__ __attribute__((aligned(16))) float raw[16][100];
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
@@ -310,10 +312,15 @@ split_planes_kernel(const float* __restrict__ x, const int* __restrict__ idx, _F
                     const int64_t col = (int64_t)s * 96 + 4 * c4;
                     if (col + 3 < 3 * N_tot) {
                         v = *reinterpret_cast<const f32x4*>(x + t * 3 * N_tot + col);
+                        if (mean) {
+                            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + col);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = __fsub_rn(v[u], mu[u]);
+                        }
                     } else {
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            if (col + u < 3 * N_tot) v[u] = x[t * 3 * N_tot + col + u];
+                            if (col + u < 3 * N_tot) v[u] = __fsub_rn(x[t * 3 * N_tot + col + u], mean ? mean[col + u] : 0.f);
                     }
                 }
                 *reinterpret_cast<f32x4*>(&raw[row][4 * c4]) = v;
@@ -330,6 +337,7 @@ split_planes_kernel(const float* __restrict__ x, const int* __restrict__ idx, _F
             if (t < T && pos < n_g) {
                 const int64_t atom = idx ? idx[pos] : pos;
                 v = x[(t * N_tot + atom) * 3 + comp];
+                if (mean) v = __fsub_rn(v, mean[atom * 3 + comp]);
             }
             raw[row][col] = v;
         }
@@ -348,18 +356,18 @@ split_planes_kernel(const float* __restrict__ x, const int* __restrict__ idx, _F
     }
 }
 
-int launch_split_planes(psa_ctx* c, const float* d_x, const int* d_idx, void* d_planes, int64_t T, int64_t N_tot, int n_g,
-                        int A_pad, float vscale) {
+int launch_split_planes(psa_ctx* c, const float* d_x, const float* d_mean, const int* d_idx, void* d_planes, int64_t T,
+                        int64_t N_tot, int n_g, int A_pad, float vscale) {
     const int     n_stage = A_pad / K1_BA;
     const int64_t n_fg = (T + 15) / 16;
     PSA_REQUIRE(n_stage > 0 && n_fg > 0 && vscale > 0.f, "bad split geometry");
     dim3 grid((unsigned)n_stage, (unsigned)(n_fg < 4096 ? n_fg : 4096));
     if (d_idx == nullptr && n_g == N_tot && N_tot % 4 == 0)
-        hipLaunchKernelGGL(split_planes_kernel<true>, grid, dim3(192), 0, c->stream, d_x, d_idx, (_Float16*)d_planes, T, N_tot,
-                           n_g, n_stage, n_fg, vscale);
+        hipLaunchKernelGGL(split_planes_kernel<true>, grid, dim3(192), 0, c->stream, d_x, d_mean, d_idx, (_Float16*)d_planes, T,
+                           N_tot, n_g, n_stage, n_fg, vscale);
     else
-        hipLaunchKernelGGL(split_planes_kernel<false>, grid, dim3(192), 0, c->stream, d_x, d_idx, (_Float16*)d_planes, T, N_tot,
-                           n_g, n_stage, n_fg, vscale);
+        hipLaunchKernelGGL(split_planes_kernel<false>, grid, dim3(192), 0, c->stream, d_x, d_mean, d_idx, (_Float16*)d_planes, T,
+                           N_tot, n_g, n_stage, n_fg, vscale);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
 }

@@ -204,25 +204,29 @@ absmax_bits_kernel(const float4* __restrict__ x4, int64_t n4, const float* __res
 // The same per column block of 32 atoms (over all frames): an index-list group takes its scale from
 // the blocks its atoms sit in, so that a group of slow atoms is not scaled by a fast atom elsewhere.
 __global__ void __launch_bounds__(256)
-absmax_blocks_kernel(const float* __restrict__ x, int64_t T, int64_t N, unsigned* __restrict__ out) {
+absmax_blocks_kernel(const float* __restrict__ x, const float* __restrict__ mean, int64_t T, int64_t N,
+                     unsigned* __restrict__ out) {
+    // mean (N,3), may be null: the magnitudes are those of x - mean (displacement mode, sed_calculator.py:70)
     const int     fr = threadIdx.x >> 7, e = threadIdx.x & 127;      // two frame rows per pass, 96 floats each
     const int64_t col = (int64_t)blockIdx.x * 96 + e;
     unsigned      m = 0;
-    if (e < 96 && col < 3 * N)
+    if (e < 96 && col < 3 * N) {
+        const float mu = mean ? mean[col] : 0.f;
         for (int64_t t = 2 * (int64_t)blockIdx.y + fr; t < T; t += 2 * (int64_t)gridDim.y)
-            m = max(m, __float_as_uint(x[t * 3 * N + col]) & 0x7fffffffu);
+            m = max(m, __float_as_uint(__fsub_rn(x[t * 3 * N + col], mu)) & 0x7fffffffu);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out + blockIdx.x, m);
 }
 
-int launch_absmax_blocks(psa_ctx* c, const float* d_x, int64_t T, int64_t N, unsigned* d_out) {
+int launch_absmax_blocks(psa_ctx* c, const float* d_x, const float* d_mean, int64_t T, int64_t N, unsigned* d_out) {
     const int64_t n_blocks = (N + 31) / 32;
     PSA_REQUIRE(n_blocks < (1ll << 31), "too many atoms");
     PSA_HIP_CHECK(hipMemsetAsync(d_out, 0, (size_t)n_blocks * sizeof(unsigned), c->stream));
     const int64_t rows = (T + 1) / 2;
     dim3 grid((unsigned)n_blocks, (unsigned)(rows < 64 ? rows : 64));
-    hipLaunchKernelGGL(absmax_blocks_kernel, grid, dim3(256), 0, c->stream, d_x, T, N, d_out);
+    hipLaunchKernelGGL(absmax_blocks_kernel, grid, dim3(256), 0, c->stream, d_x, d_mean, T, N, d_out);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
 }

@@ -142,6 +142,8 @@ struct PlaneSet {
     bool                 all_atoms = true;
     std::vector<int32_t> idx;            // the atom list (compacted order), empty when all_atoms
     uint64_t             idx_hash = 0;
+    bool                 displaced = false;   // the planes hold slot - mean (displacement mode)
+    std::vector<float>   mean;                // ... with this mean (N,3)
     int64_t              T = 0, n_fg = 0;
     int                  n_g = 0, A_pad = 0;
     float                vscale = 0.f;
@@ -174,6 +176,10 @@ struct psa_ctx {
     psa::DataSlot slot[PSA_NUM_SLOTS + 1];
     std::vector<float> disp_mean;        // the mean the displacement array was built with
     uint64_t           disp_source = 0;  // generation of the positions slot it was built from
+    // largest |positions - mean| per 32-atom column block (scale of displacement-mode planes)
+    std::vector<unsigned> disp_block_absmax;
+    std::vector<float>    disp_abs_mean;
+    uint64_t              disp_abs_source = ~0ull;
 
     // per-call scratch
     psa::DevBuf d_kvec, d_mean_all, d_idx, d_mean_g, d_phase, d_qwork, d_fft_work, d_tables, d_absmax;
@@ -224,7 +230,7 @@ int launch_fill_synthetic(psa_ctx* c, float* d_v, int64_t T, int64_t N, uint64_t
 int launch_mean_over_frames(psa_ctx* c, const float* d_x, int64_t T, int64_t N, float* d_mean);
 int launch_subtract_mean(psa_ctx* c, const float* d_x, const float* d_mean, float* d_out, int64_t T, int64_t N);
 int launch_absmax_bits(psa_ctx* c, const float* d_x, int64_t n, unsigned* d_out, bool reset = true);
-int launch_absmax_blocks(psa_ctx* c, const float* d_x, int64_t T, int64_t N, unsigned* d_out);
+int launch_absmax_blocks(psa_ctx* c, const float* d_x, const float* d_mean, int64_t T, int64_t N, unsigned* d_out);
 
 // --- k1_mfma.hip / k1_wave.hip
 int  k1_mfma_block_rows(int K);                    // M block of the variant chosen for K
@@ -255,8 +261,8 @@ int    launch_k1_pair(psa_ctx* c, const float* d_v, const void* d_phase, const i
 
 // --- k1_planes.hip ("2 x f16" from cached split planes: every kind of group)
 int    k1_planes_block_rows(int K);
-int    launch_split_planes(psa_ctx* c, const float* d_x, const int* d_idx, void* d_planes, int64_t T, int64_t N_tot,
-                           int n_g, int A_pad, float vscale);
+int    launch_split_planes(psa_ctx* c, const float* d_x, const float* d_mean, const int* d_idx, void* d_planes, int64_t T,
+                           int64_t N_tot, int n_g, int A_pad, float vscale);
 int    launch_k1_planes(psa_ctx* c, const void* d_planes, const void* d_phase, float2* d_q, const ProjGeom& g,
                         int64_t n_fg);
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Displacement mode (use_displacements=True) at configuration-3 size on the GPU box: the synthetic
-array stands in for positions; first call (builds positions - mean in HBM), later calls, and the
+array stands in for positions; first call (builds the split planes of positions - mean in HBM), later calls, and the
 float32 kernel that subtracts while staging."""
 import sys
 import time
@@ -20,7 +20,7 @@ for call in range(2):
     print(f"mean over frames (bit-exact sequential float32 sum): {(time.perf_counter() - t0) * 1e3:.2f} ms", flush=True)
 kmax = 2 * np.pi / synth.A_SI / np.sqrt(2)
 vecs = (np.linspace(0, kmax, 256, dtype=np.float32)[:, None] * np.array([1, 1, 0], np.float32) / np.sqrt(2)).astype(np.float32)
-for name, sel in (("split kernels on the materialised array", _hip.K1_AUTO), ("float32 kernel, subtract while staging", _hip.K1_MFMA32)):
+for name, sel in (("2xf16 kernel on planes built from positions - mean", _hip.K1_AUTO), ("float32 kernel, subtract while staging", _hip.K1_MFMA32)):
     eng.set_k1(sel)
     for call in range(3):
         eng.k1_stats()
