@@ -144,10 +144,11 @@ int psa_mean_positions(psa_ctx* ctx, int slot, float* mean_host /* (N,3) */);
  *                  G = 1 meaning "all N atoms in order"
  *   group_off    : (G+1) int64 offsets into group_idx (ignored when group_idx NULL)
  * Without PSA_F_INTENSITY, G must be 1.
- * The first velocity-mode projection after an upload makes one extra pass over the slot (its
- * largest magnitude, from which the float16 projection kernel takes a power-of-two scale; per
- * 32-atom column block for index-list groups) and blocks until it is read back; later calls are
- * asynchronous on the context's stream.
+ * The first projection of a group after an upload does work that is cached afterwards: one pass for
+ * the largest magnitude of the data (the power-of-two scale of the float16 kernels; per 32-atom
+ * column block for index-list groups; of slot - mean in displacement mode) with a blocking
+ * read-back -- psa_sed_project_upload folds it into the upload -- and, under PSA_OPT_PLANES, the
+ * build of the group's split planes.  Later calls are asynchronous on the context's stream.
  */
 int psa_sed_project(psa_ctx* ctx, int slot,
                     const float* mean_pos_all,

@@ -1,5 +1,11 @@
-// C ABI of libpsa_hip.so (declared in include/psa_hip.h): context, trajectory residency,
-// the project -> FFT -> epilogue pipeline, k-shard gather over RCCL.
+// C ABI of libpsa_hip.so (declared in include/psa_hip.h).  In file order:
+//   context, error text, stage / one-off timing, rocFFT plans, magnitude passes
+//   the plane cache (get_planes), projection geometry (make_geom), phase table + projection launch
+//   the host -> device staging pipeline (CopyPool, staged_upload)
+//   extern "C": context and options, trajectory residency, synthetic fill, mean, displacements
+//   the hot path: psa_sed_project / _project_upload / _finalize / _calculate (pipelined) / _single_bin
+//   slab access, result intensity / chiral phase, timings, diagnostics
+//   sharding over RCCL: communicator, gather (k rows), frame sharding (psa_sed_fs_*)
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
