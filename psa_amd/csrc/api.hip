@@ -506,6 +506,10 @@ std::mutex g_copy_pool_mutex;                        // one upload at a time fee
 
 int stager_init(psa_ctx* c, size_t chunk_bytes) {
     Stager& st = c->stager;
+    if (std::getenv("PSA_UPLOAD_NO_STAGING")) {                  // (tests: the path a locked-memory limit takes)
+        set_error("page-locked staging disabled");
+        return PSA_ENOMEM;
+    }
     if (!st.copy_stream) PSA_HIP_CHECK(hipStreamCreateWithFlags(&st.copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i)
         if (!st.freed[i]) PSA_HIP_CHECK(hipEventCreateWithFlags(&st.freed[i], hipEventDisableTiming));
@@ -545,7 +549,29 @@ int staged_upload(psa_ctx* c, float* dev, const float* host, int64_t T, int64_t 
     if (frames >= 64) frames = frames / 64 * 64;               // whole projection tiles
     else if ((size_t)64 * row <= ((size_t)256 << 20)) frames = 64;
     frames = std::min(std::max<int64_t>(frames, 1), T);        // (very wide rows: fewer frames per chunk)
-    PSA_TRY(stager_init(c, (size_t)frames * row));
+    if (stager_init(c, (size_t)frames * row) != PSA_OK) {
+        // no page-locked memory to be had (locked-memory limit): plain copies from the pageable source,
+        // the chunk callback still runs behind each of them
+        (void)hipGetLastError();
+        stager_release(c);
+        HostTimer  ht(&c->oneoff_ms[3]);
+        hipEvent_t ev = nullptr;
+        PSA_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        int rc = PSA_OK;
+        for (int64_t t0 = 0; t0 < T && rc == PSA_OK; t0 += frames) {
+            const int64_t nt = std::min(frames, T - t0);
+            if (hipMemcpyAsync((char*)dev + (size_t)t0 * row, (const char*)host + (size_t)t0 * row, (size_t)nt * row,
+                               hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipEventRecord(ev, c->stream) != hipSuccess)
+                rc = PSA_EHIP;
+            else if (on_chunk)
+                rc = on_chunk(t0, nt, ev);
+        }
+        if (hipStreamSynchronize(c->stream) != hipSuccess && rc == PSA_OK) rc = PSA_EHIP;
+        (void)hipEventDestroy(ev);
+        if (rc == PSA_EHIP) set_error("host -> device copy failed: %s", hipGetErrorString(hipGetLastError()));
+        return rc;
+    }
     Stager&                     st = c->stager;
     HostTimer                   ht(&c->oneoff_ms[3]);
     std::lock_guard<std::mutex> pool_lock(g_copy_pool_mutex);

@@ -492,3 +492,20 @@ def test_very_long_k_lists_are_projected_in_blocks(fresh_engine, monkeypatch):
     np.testing.assert_allclose(eng.finalize(96, 300, True), whole_inc, rtol=1e-6)
     ref, _, _ = O.calculate(pos, vel, types, 0.002, kv)
     assert rel_max(whole, ref) <= TOL
+
+
+def test_upload_without_page_locked_staging(fresh_engine, trajs, monkeypatch):
+    """If no page-locked memory can be had the upload falls back to plain copies; the streamed
+    first call still projects chunk by chunk."""
+    monkeypatch.setenv("PSA_UPLOAD_NO_STAGING", "1")
+    monkeypatch.setenv("PSA_UPLOAD_CHUNK_MIB", "1")
+    eng = fresh_engine
+    d = trajs["b"]
+    calc = make_calculator(d).attach(engine=eng)
+    mags, vecs = calc.get_k_path([1, 1, 0], 2.0, 20)
+    ref, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], d["dt_ps"], vecs)
+    assert rel_max(calc.calculate(mags, vecs).sed, ref) <= TOL          # psa_sed_project_upload
+    eng.invalidate()
+    eng.ensure_resident(0, d["velocities"])                               # psa_data_upload
+    np.testing.assert_array_equal(eng.download(0, 0, 64), d["velocities"])
+    assert rel_max(calc.calculate(mags, vecs).sed, ref) <= TOL
