@@ -509,3 +509,51 @@ def test_upload_without_page_locked_staging(fresh_engine, trajs, monkeypatch):
     eng.ensure_resident(0, d["velocities"])                               # psa_data_upload
     np.testing.assert_array_equal(eng.download(0, 0, 64), d["velocities"])
     assert rel_max(calc.calculate(mags, vecs).sed, ref) <= TOL
+
+
+def test_new_entry_points_reject_misuse(fresh_engine, trajs):
+    """Every round-2 ABI function validates its arguments and the call sequence (PSA_EINVAL /
+    PSA_ESTATE -> PsaHipError, index errors -> ValueError like the reference) and leaves the context usable."""
+    from psa_amd import _hip
+    eng = fresh_engine
+    d = trajs["a"]
+    vel, mean = d["velocities"], O.mean_positions(d["positions"])
+    kv = _kvecs(20)
+    with pytest.raises(_hip.PsaHipError, match="no frame-sharded projection"):
+        eng.fs_finish(True)
+    with pytest.raises(_hip.PsaHipError, match="holds no array"):
+        eng.fs_project(0, mean, kv, None, 0, 128, 0, 20)
+    eng.ensure_resident(0, vel)
+    with pytest.raises(_hip.PsaHipError, match="outside"):
+        eng.fs_project(0, mean, kv, None, 0, 128, 15, 10)                 # k rows 15..25 of 20
+    with pytest.raises(_hip.PsaHipError):
+        eng.fs_project(0, mean, kv, None, 0, 64, 0, 20)                   # T_total < the slot's frames
+    with pytest.raises(ValueError, match="out of bounds"):
+        eng.fs_project(0, mean, kv, np.array([0, 64], np.int32), 0, 128, 0, 20)
+    eng.fs_project(0, mean, kv, None, 0, 128, 0, 20)
+    with pytest.raises(_hip.PsaHipError, match="tile the trajectory"):
+        eng.fs_exchange([0], [64], [0], [20])
+    with pytest.raises(_hip.PsaHipError, match="row range"):
+        eng.fs_exchange([0], [128], [0], [19])
+    with pytest.raises(_hip.PsaHipError):
+        eng.fs_read(10, 11, 128)
+    with pytest.raises(_hip.PsaHipError):
+        eng.fs_write(100, np.zeros((20, 3, 64), np.complex64))
+    eng.fs_exchange([0], [128], [0], [20])
+    eng.fs_finish(True)
+    ref, _, _ = O.calculate(d["positions"], vel, d["types"], d["dt_ps"], kv)
+    assert rel_max(eng.finalize(128, 20, False), ref) <= TOL               # ... and still works
+    with pytest.raises(ValueError, match="out of bounds"):
+        eng.single_bin(0, mean, kv[0], np.array([1, 2, 99], np.int32), 3)
+    with pytest.raises(_hip.PsaHipError, match="frame range"):
+        eng.debug_project_only(0, mean, kv, None, frames=(100, 64))
+    with pytest.raises(_hip.PsaHipError):
+        eng.set_option(_hip.OPT_PLANES_MIN_K, 0)
+    with pytest.raises(_hip.PsaHipError):
+        eng.set_option(_hip.OPT_PLANES_BUDGET, -5)
+    with pytest.raises(ValueError, match="out of bounds"):
+        eng.project_upload(0, np.array(vel), mean, kv, [np.array([0, 1, 64])], 0)
+    eng.project(0, mean, kv)                                                # rejected before the slot was touched:
+    assert rel_max(eng.finalize(128, 20, False), ref) <= TOL               # the old array is still there, whole
+    eng.project_upload(0, vel, mean, kv, None, 0)
+    assert rel_max(eng.finalize(128, 20, False), ref) <= TOL
