@@ -139,6 +139,12 @@ CALC_WIDE_CASES = [
          kw=dict(basis_atom_types=[1, 2], summation_mode="incoherent")),
     dict(name="w_nonpow2_T100_k24", traj="c", k=("path", "z", 2.0, 24, None)),
     dict(name="w_grid_xy_6x7", traj="a", k=("grid", "xy", (-1.5, 1.5), (-1.0, 1.0), 6, 7, 0.25)),
+    dict(name="w_grid_zx_inc_5x8", traj="a", k=("grid", "zx", (-0.5, 1.5), (-1.0, 1.0), 5, 8, -0.3),
+         kw=dict(basis_atom_types=[1, 2], summation_mode="incoherent")),
+    dict(name="w_idx_nested_inc_k40", traj="a", k=_K40,
+         kw=dict(basis_atom_indices=[list(range(0, 40)), list(range(30, 64)) + [1, 1]], summation_mode="incoherent")),
+    dict(name="w_displacements_idx_k40", traj="b", k=("path", [1, 1, 0], 4.0, 40, None), ctor=dict(use_displacements=True),
+         kw=dict(basis_atom_indices=nd(list(range(0, 128, 3)) + [5, 5, 127]))),
 ]
 
 
