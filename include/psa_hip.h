@@ -91,7 +91,9 @@ int         psa_set_k1(psa_ctx* ctx, int selector);     /* PSA_K1_* */
  *                             projected by the on-the-fly kernels.  The float32 slot is never dropped.
  *   PSA_OPT_PLANES_EAGER  [0] 1 = build an index-list group's planes on its first projection
  *                             (default: on the second with the same list; "all atoms" always first)
- *   PSA_OPT_PLANES_MIN_K  [17] shortest k-list that is projected from planes */
+ *   PSA_OPT_PLANES_MIN_K  [17] shortest k-list for which a group's planes are BUILT (a shorter list
+ *                             uses them when they exist; otherwise the "3 x bf16" kernel on the
+ *                             float32 array, which is HBM-bound at the same rate) */
 #define PSA_OPT_PLANES         0
 #define PSA_OPT_PLANES_BUDGET  1
 #define PSA_OPT_PLANES_EAGER   2

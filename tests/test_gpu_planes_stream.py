@@ -75,10 +75,12 @@ def test_plane_cache_policy(fresh_engine, trajs):
     ref_idx = O.project_group(vel[:, idx, :], O.phase_table(kv, mean[idx]))
     eng.ensure_resident(0, vel)
     assert eng.plane_cache()[0] == 0
-    eng.debug_project_only(0, mean, kv[:8])                      # short k-list: bf16 kernel, no planes
+    s1 = eng.debug_project_only(0, mean, kv[:8])                 # short k-list: bf16 kernel, no planes built
     assert eng.plane_cache()[0] == 0
     a1 = eng.debug_project_only(0, mean, kv)
     assert eng.plane_cache()[0] == 1
+    s2 = eng.debug_project_only(0, mean, kv[:8])                 # ... but used once they exist (32-row variant)
+    assert eng.plane_cache()[0] == 1 and rel_max(s2, s1) < 2e-6 and not np.array_equal(s1, s2)
     i1 = eng.debug_project_only(0, mean, kv, idx)                # first sight of the list: gather kernel
     assert eng.plane_cache()[0] == 1
     i2 = eng.debug_project_only(0, mean, kv, idx)                # second: compacted planes
