@@ -411,7 +411,7 @@ def main():
         k1_avg_ms = k1_ms / max(1, k1_n)
         flops = FLOP_PER_UNIT * per_launch_units
         algo_bytes = 12.0 * n_launch_atoms * t_local + 8.0 * k_local * n_launch_atoms + 24.0 * t_local * k_local
-        # the library's rule (api.hip get_planes / make_geom): "2 x f16" for groups with more than 16
+        # the library's rule (api_project.hip get_planes / make_geom): "2 x f16" for groups with more than 16
         # k-vectors -- from cached planes ("auto") or splitting in the kernel -- "3 x bf16" below
         if args.k1 == "mfma32":
             products, kernel_name, dtype = 1, "k1_mfma_kernel (k-projection, exact-fp32 MFMA)", "f32"

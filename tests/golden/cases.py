@@ -109,7 +109,7 @@ CALC_CASES = [
 ]
 
 # `calculate` cases with more than 16 k-vectors: these are the ones the product-default "2 x f16"
-# projection kernel serves (api.hip make_geom: K > 16), in all its forms -- 64-row blocks (K <= 32)
+# projection kernel serves (api_project.hip make_geom: K > 16), in all its forms -- 64-row blocks (K <= 32)
 # and 128-row blocks, row DMA (all atoms in order) and gather DMA (index lists / type groups),
 # the materialised-displacement array, phases up to ~200 rad.  The reference output is stored as
 # the full intensity plus every WIDE_SED_STRIDE-th frequency row of `sed` (keeps the fixture small).
