@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PSA_HIP_ABI_VERSION 2
+#define PSA_HIP_ABI_VERSION 3
 
 /* error codes */
 #define PSA_OK          0
@@ -98,6 +98,22 @@ int         psa_set_k1(psa_ctx* ctx, int selector);     /* PSA_K1_* */
 #define PSA_OPT_PLANES_BUDGET  1
 #define PSA_OPT_PLANES_EAGER   2
 #define PSA_OPT_PLANES_MIN_K   3
+/*   PSA_OPT_FOLD_PAIRS    [1] when the whole k-list is given to one device, k-vectors whose exact
+ *                             negation (or an identical twin) is also in the list are not projected:
+ *                             S(-k)[w] = conj S(k)[(T-w) mod T] holds bit for bit in the reference's
+ *                             arithmetic (float32 phase argument odd in k, real data), so the partner's
+ *                             columns are written by the epilogue from the one projection.  A k-grid
+ *                             symmetric about Gamma (examples/k_grid_heatmap_example.py:33-38) costs
+ *                             half its projections and FFTs.  0 = project every vector. */
+#define PSA_OPT_FOLD_PAIRS     4
+/*   PSA_OPT_FFT_PRIME     [1] when a trajectory of T frames becomes resident (psa_data_upload /
+ *                             psa_data_alloc) a host thread builds a one-k-vector rocFFT plan of length T,
+ *                             so that rocFFT's run-time kernel compilation for that length happens beside
+ *                             the upload instead of inside the first calculation.  Independently of this,
+ *                             psa_create points ROCFFT_RTC_CACHE_PATH (unless set) at
+ *                             $PSA_CACHE_DIR | $XDG_CACHE_HOME/psa_amd | $HOME/.cache/psa_amd so that later
+ *                             processes load the compiled kernels instead of compiling them again. */
+#define PSA_OPT_FFT_PRIME      5
 int         psa_set_option(psa_ctx* ctx, int option, int64_t value);
 /* device name / CU count / HBM bytes of the context's GPU */
 int         psa_device_info(psa_ctx* ctx, char* name, int name_len,
@@ -175,14 +191,34 @@ int psa_sed_project_upload(psa_ctx* ctx, int slot, const float* host, int64_t T,
  * (sed_calculator.py:277) or (T,K) float32 (:280) -- and copy it to out_host
  * (may be NULL: the result then only exists on the device, see psa_result_*).
  * out_bytes is the size of the caller's buffer and must be exactly the result's
- * (24*T*K or 4*T*K): a mismatch is PSA_EINVAL, nothing is copied. */
-int psa_sed_finalize(psa_ctx* ctx, void* out_host, size_t out_bytes);
+ * (24*T*K or 4*T*K): a mismatch is PSA_EINVAL, nothing is copied.
+ * out_intensity (may be NULL; complex results only): (T,K) float32 = sum_c |S|^2, i.e. SED.intensity
+ * (src/psa/core/sed.py:22-24) of this very result -- produced by the same pass over the result (the
+ * tile is in LDS anyway) and copied beside it; out_intensity_bytes must be 4*T*K. */
+int psa_sed_finalize(psa_ctx* ctx, void* out_host, size_t out_bytes,
+                     float* out_intensity, size_t out_intensity_bytes);
 
-/* one-call convenience: project all K on this device, finalize, copy out */
+/* one-call convenience: project all K on this device, finalize, copy out.  A complex result of
+ * >= 192 k-vectors leaves block by block (project -> FFT -> transpose -> D2H on a copy stream while the
+ * next block is projected).  out_intensity as for psa_sed_finalize. */
 int psa_sed_calculate(psa_ctx* ctx, int slot, const float* mean_pos_all,
                       const float* k_vectors, int64_t K,
                       const int32_t* group_idx, const int64_t* group_off, int32_t G,
-                      int32_t flags, void* out_host, size_t out_bytes);
+                      int32_t flags, void* out_host, size_t out_bytes,
+                      float* out_intensity, size_t out_intensity_bytes);
+
+/* Pair folding (PSA_OPT_FOLD_PAIRS) as a service for callers that split a k-list themselves
+ * (psa_amd/dist.py): kmap[i] = row of k-vector i among the n_unique vectors that need projecting
+ * (unique_idx[r] = position of row r's vector in the input list), with bit 31 set when vector i is
+ * the exact negation of that row's vector.  No context, no GPU. */
+#define PSA_KMAP_MIRROR 0x80000000u
+int psa_k_pairs(const float* k_vectors, int64_t K, int32_t* kmap /* K */,
+                int32_t* unique_idx /* K, first n_unique valid */, int64_t* n_unique);
+/* ... and the map of a result whose slab rows the caller projected from the folded list (every rank
+ * that finalizes installs it after its psa_sed_project / psa_sed_gather): psa_sed_finalize then
+ * returns K_out columns, column i from slab row kmap[i] & ~PSA_KMAP_MIRROR, mirrored in frequency
+ * and conjugated where bit 31 is set. */
+int psa_sed_set_kmap(psa_ctx* ctx, const int32_t* kmap, int64_t K_out);
 
 /* One (k, omega) bin: S[c] = FFT_t(q)[i_w] / T for ONE k-vector and one atom group, as 3
  * complex64 -- what iSED consumes of a group's spectrum (sed_calculator.py:483, :494-499: only
@@ -198,8 +234,9 @@ int psa_sed_single_bin(psa_ctx* ctx, int slot, const float* mean_pos_all, const 
 int psa_slab_read(psa_ctx* ctx, int64_t row0, int64_t nrows, void* host);
 int psa_slab_write(psa_ctx* ctx, int64_t row0, int64_t nrows, const void* host);
 
-/* SED.intensity of the finalized complex result, on the device:
- * (T,K) float32 = sum_c |S|^2   (src/psa/core/sed.py:22-24) */
+/* SED.intensity of the finalized complex result, (T,K) float32 = sum_c |S|^2 (src/psa/core/sed.py:22-24):
+ * psa_sed_finalize / psa_sed_calculate leave it on the device next to the result; this copies it out
+ * (out_host NULL: only makes sure it exists). */
 int psa_result_intensity(psa_ctx* ctx, float* out_host /* (T,K) */, size_t out_bytes);
 /* chiral phase, option "C", of components (c1, c2) of the finalized complex
  * result: (T,K) float32           (sed_calculator.py:344-350) */

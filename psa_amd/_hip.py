@@ -21,8 +21,9 @@ LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libpsa_hip.so"
 SLOT_VELOCITIES, SLOT_POSITIONS = 0, 1
 F_DISPLACEMENTS, F_INTENSITY = 0x1, 0x2
 K1_AUTO, K1_WAVE, K1_MFMA32, K1_SPLIT_BF16 = 0, 1, 2, 3
-OPT_PLANES, OPT_PLANES_BUDGET, OPT_PLANES_EAGER, OPT_PLANES_MIN_K = 0, 1, 2, 3
-ABI_VERSION = 2
+OPT_PLANES, OPT_PLANES_BUDGET, OPT_PLANES_EAGER, OPT_PLANES_MIN_K, OPT_FOLD_PAIRS, OPT_FFT_PRIME = 0, 1, 2, 3, 4, 5
+KMAP_MIRROR = 0x80000000
+ABI_VERSION = 3
 UNIQUE_ID_BYTES = 128
 TIMING_NAMES = ("h2d", "phase", "project", "fft", "epilogue", "gather", "transpose", "d2h")
 
@@ -56,9 +57,11 @@ SIGNATURES = {
                                   _i32p, _i64p, C.c_int32, C.c_int32]),
     "psa_sed_project_upload": (C.c_int, [_ctx, C.c_int, _f32p, C.c_int64, C.c_int64, _f32p, _f32p, C.c_int64,
                                          _i32p, _i64p, C.c_int32, C.c_int32]),
-    "psa_sed_finalize": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
+    "psa_sed_finalize": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, _f32p, C.c_size_t]),
     "psa_sed_calculate": (C.c_int, [_ctx, C.c_int, _f32p, _f32p, C.c_int64, _i32p, _i64p,
-                                    C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
+                                    C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, _f32p, C.c_size_t]),
+    "psa_k_pairs": (C.c_int, [_f32p, C.c_int64, _i32p, _i32p, _i64p]),
+    "psa_sed_set_kmap": (C.c_int, [_ctx, _i32p, C.c_int64]),
     "psa_sed_single_bin": (C.c_int, [_ctx, C.c_int, _f32p, _f32p, _i32p, C.c_int64, C.c_int32, C.c_int64, _f32p]),
     "psa_slab_read": (C.c_int, [_ctx, C.c_int64, C.c_int64, C.c_void_p]),
     "psa_slab_write": (C.c_int, [_ctx, C.c_int64, C.c_int64, C.c_void_p]),
@@ -141,6 +144,17 @@ def device_count() -> int:
     return n.value
 
 
+def k_pairs(k_vectors):
+    """(kmap uint32 (K,), unique_idx int32 (U,)): pairs (k, -k) and repeated vectors of a k-list
+    (psa_k_pairs; bit 31 of kmap = the vector is the exact negation of row kmap & 0x7fffffff)."""
+    kv = _as_f32(k_vectors, (3,)) if len(k_vectors) else np.zeros((0, 3), np.float32)
+    K = kv.shape[0]
+    kmap, uidx, n = np.zeros(K, np.int32), np.zeros(K, np.int32), C.c_int64(0)
+    _check(load_library().psa_k_pairs(_f32(kv), K, kmap.ctypes.data_as(_i32p), uidx.ctypes.data_as(_i32p), C.byref(n)),
+           "psa_k_pairs")
+    return kmap.view(np.uint32), uidx[:n.value].copy()
+
+
 def pack_groups(groups: Optional[Sequence[np.ndarray]]):
     """list of index arrays -> (idx int32, off int64, G) for the ABI; None -> all atoms."""
     if groups is None:
@@ -169,6 +183,7 @@ class _PinnedPool:
         self._idle_bytes = 0
         self._live_bytes = 0
         self._lock = threading.Lock()
+        self.stats = {"recycled": 0, "allocated": 0, "pageable": 0}    # results of >= min_bytes, by how they were served
 
     def _give_back(self, address: int, size: int):
         with self._lock:
@@ -187,6 +202,7 @@ class _PinnedPool:
         size = -(-nbytes // self.granule) * self.granule
         with self._lock:
             if self._live_bytes + size > self.max_live_bytes:
+                self.stats["pageable"] += 1
                 return np.empty(shape, dtype)
             self._live_bytes += size
             stack = self._idle.get(size)
@@ -200,8 +216,12 @@ class _PinnedPool:
             except PsaHipError:             # e.g. the locked-memory limit: an ordinary array will do
                 with self._lock:
                     self._live_bytes -= size
+                    self.stats["pageable"] += 1
                 return np.empty(shape, dtype)
             address = p.value
+            self.stats["allocated"] += 1
+        else:
+            self.stats["recycled"] += 1
         block = (C.c_char * size).from_address(address)
         weakref.finalize(block, self._give_back, address, size)     # block dies with its last view
         return np.frombuffer(block, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
@@ -424,16 +444,19 @@ class Engine:
             off.ctypes.data_as(_i64p) if off is not None else None, G, flags), "psa_sed_project_upload")
         self._note_resident(slot, a)
 
-    def finalize(self, T: int, K: int, intensity: bool, fetch: bool = True) -> Optional[np.ndarray]:
+    def finalize(self, T: int, K: int, intensity: bool, fetch: bool = True, with_intensity: bool = False):
         """(T,K) / (T,K,3) is what the caller expects: the library refuses (PSA_EINVAL) if the
-        result resident on the device has another size."""
+        result resident on the device has another size.  with_intensity (complex results): returns
+        (sed, sum_c |sed|^2) -- the (T,K) float32 intensity comes out of the same pass on the device."""
         if not fetch:
-            _check(self._lib.psa_sed_finalize(self._h, None, 0), "psa_sed_finalize")
-            return None
+            _check(self._lib.psa_sed_finalize(self._h, None, 0, None, 0), "psa_sed_finalize")
+            return (None, None) if with_intensity else None
         out = pinned_empty((T, K), np.float32) if intensity else pinned_empty((T, K, 3), np.complex64)
-        _check(self._lib.psa_sed_finalize(self._h, out.ctypes.data_as(C.c_void_p), out.nbytes),
-               "psa_sed_finalize")
-        return out
+        inten = pinned_empty((T, K), np.float32) if with_intensity and not intensity else None
+        _check(self._lib.psa_sed_finalize(self._h, out.ctypes.data_as(C.c_void_p), out.nbytes,
+                                          _f32(inten) if inten is not None else None,
+                                          inten.nbytes if inten is not None else 0), "psa_sed_finalize")
+        return (out, inten) if with_intensity else out
 
     def single_bin(self, slot, mean_pos_all, k_vector, idx, i_w: int, flags=0) -> np.ndarray:
         """S[i_w, k, :] of one k-vector and one atom group as (3,) complex64."""
@@ -446,22 +469,32 @@ class Engine:
             0 if ii is None else len(ii), flags, int(i_w), out.ctypes.data_as(_f32p)), "psa_sed_single_bin")
         return out
 
-    def calculate(self, slot, mean_pos_all, k_vectors, groups=None, flags=0) -> np.ndarray:
+    def calculate(self, slot, mean_pos_all, k_vectors, groups=None, flags=0, with_intensity: bool = False):
         """project + finalize in one library call (psa_sed_calculate): a complex result of a long
-        k-list is produced block by block, each block's D2H copy overlapping the next projection."""
+        k-list is produced block by block, each block's D2H copy overlapping the next projection.
+        with_intensity (complex results): returns (sed, sum_c |sed|^2), the second array computed on the
+        device in the pass that writes the first."""
         T, _ = self.shape(slot)
         mean = _as_f32(mean_pos_all, (3,))
         kv = _as_f32(k_vectors, (3,))
         idx, off, G = pack_groups(groups)
         K = kv.shape[0]
-        out = pinned_empty((T, K), np.float32) if flags & F_INTENSITY else pinned_empty((T, K, 3), np.complex64)
+        intensity = bool(flags & F_INTENSITY)
+        out = pinned_empty((T, K), np.float32) if intensity else pinned_empty((T, K, 3), np.complex64)
+        inten = pinned_empty((T, K), np.float32) if with_intensity and not intensity else None
         self.result_serial += 1
         _check(self._lib.psa_sed_calculate(
             self._h, slot, _f32(mean), _f32(kv), K,
             idx.ctypes.data_as(_i32p) if idx is not None else None,
             off.ctypes.data_as(_i64p) if off is not None else None, G, flags,
-            out.ctypes.data_as(C.c_void_p), out.nbytes), "psa_sed_calculate")
-        return out
+            out.ctypes.data_as(C.c_void_p), out.nbytes,
+            _f32(inten) if inten is not None else None, inten.nbytes if inten is not None else 0), "psa_sed_calculate")
+        return (out, inten) if with_intensity else out
+
+    def set_kmap(self, kmap: np.ndarray):
+        """Install the k map of a result whose slab rows were projected from a folded list (`k_pairs`)."""
+        m = np.ascontiguousarray(kmap, np.uint32).view(np.int32)
+        _check(self._lib.psa_sed_set_kmap(self._h, m.ctypes.data_as(_i32p), len(m)), "psa_sed_set_kmap")
 
     def slab_read(self, row0: int, nrows: int, T: int, intensity: bool) -> np.ndarray:
         out = np.empty((nrows, T), np.float32) if intensity else np.empty((nrows, 3, T), np.complex64)

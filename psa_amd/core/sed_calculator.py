@@ -149,24 +149,32 @@ class SEDCalculator:
         return [np.asarray(g) for g in groups]
 
     def _run_device(self, k_vectors: np.ndarray, groups, intensity: bool, mean_pos_all,
-                    fetch: bool = True) -> Optional[np.ndarray]:
+                    fetch: bool = True):
+        """(result, sum_c |result|^2 or None): the second array accompanies a complex result -- it is
+        what `SED.intensity` returns (core/sed.py:22-24), produced on the device in the pass that
+        writes the result."""
         slot, data, flags = self._data_slot()
         if intensity:
             flags |= _hip.F_INTENSITY
+        want = not intensity
         eng = self.engine
         with eng.lock:                       # project + finalize must not interleave across threads
             K = len(k_vectors)
             T = self.traj.n_frames
             if self._shard is not None and self._shard.nranks > 1:
-                return self._shard.run(slot, data, mean_pos_all, k_vectors, groups, flags, T, fetch)
-            if not eng.is_resident(slot, data):
+                out = self._shard.run(slot, data, mean_pos_all, k_vectors, groups, flags, T, fetch, with_intensity=want)
+            elif not eng.is_resident(slot, data):
                 # first call on this array: upload and project, overlapped
                 eng.project_upload(slot, data, mean_pos_all, k_vectors, groups, flags)
-                return eng.finalize(T, K, intensity, fetch)
-            if fetch:                        # one library call; long complex results leave block by block
-                return eng.calculate(slot, mean_pos_all, k_vectors, groups, flags)
-            eng.project(slot, mean_pos_all, k_vectors, groups, flags)
-            return eng.finalize(T, K, intensity, False)
+                out = eng.finalize(T, K, intensity, fetch, with_intensity=want)
+            elif fetch:                      # one library call; long complex results leave block by block
+                out = eng.calculate(slot, mean_pos_all, k_vectors, groups, flags, with_intensity=want)
+            else:
+                eng.project(slot, mean_pos_all, k_vectors, groups, flags)
+                out = eng.finalize(T, K, intensity, False, with_intensity=want)
+        if want:
+            return out if out is not None else (None, None)
+        return out, None
 
     # ------------------------------------------------------------------ the seam
     def _calculate_sed_for_group(self, k_vectors_3d: np.ndarray, group_atom_indices: np.ndarray,
@@ -177,7 +185,7 @@ class SEDCalculator:
         if idx.size == 0 or len(k_vectors_3d) == 0:
             return np.zeros((n_t, len(k_vectors_3d), 3), dtype=np.complex64)
         return self._run_device(np.asarray(k_vectors_3d), self._device_groups([idx]), False,
-                                mean_pos_all)
+                                mean_pos_all)[0]
 
     # ------------------------------------------------------------------ k generators
     def get_k_path(self, direction_spec: Union[str, int, float, List[float], Dict[str, float], np.ndarray],
@@ -321,17 +329,19 @@ class SEDCalculator:
         if n_k == 0:
             logger.warning("k_vectors_3d is empty. Returning SED object with empty SED data.")
             shape = (n_t, 0, 3) if is_complex else (n_t, 0)
-            data = np.zeros(shape, dtype=np.complex64 if is_complex else np.float32)
+            data, inten = np.zeros(shape, dtype=np.complex64 if is_complex else np.float32), None
         elif is_complex:
             # several coherent groups act as their sorted union (:297-298)
             members = np.unique(np.concatenate(groups)).astype(int) if len(groups) > 1 else groups[0]
-            data = self._run_device(np.asarray(k_vectors_3d), self._device_groups([members]), False,
-                                    mean_pos_all)
+            data, inten = self._run_device(np.asarray(k_vectors_3d), self._device_groups([members]), False,
+                                           mean_pos_all)
         else:
-            data = self._run_device(np.asarray(k_vectors_3d), self._device_groups(groups), True,
-                                    mean_pos_all)
+            data, inten = self._run_device(np.asarray(k_vectors_3d), self._device_groups(groups), True,
+                                           mean_pos_all)
         sed = SED(data, freqs, k_points_mags, k_vectors_3d, k_grid_shape=k_grid_shape,
                   is_complex=is_complex, phase=None)
+        if inten is not None and isinstance(data, np.ndarray):
+            sed._attach_intensity(inten)                 # `sed.intensity` is free: it came with the result
         from . import sed as _sed_module
         if (_sed_module._FAST_INTENSITY and is_complex and n_k and isinstance(data, np.ndarray) and data.ndim == 3
                 and self._shard is None and hasattr(self._engine, "intensity_source")):

@@ -2,6 +2,10 @@
 // (part of the C ABI of libpsa_hip.so, include/psa_hip.h; shared declarations: api_internal.h)
 #include "api_internal.h"
 
+#include <unistd.h>
+
+#include <filesystem>
+
 namespace psa {
 
 thread_local std::string g_error;
@@ -82,19 +86,53 @@ int upload(psa_ctx* c, DevBuf& b, const void* host, size_t bytes) {
     return PSA_OK;
 }
 
+static int create_plan(psa_ctx* c, int64_t T, int64_t batch, FftPlan* p) {
+    size_t len = (size_t)T;
+    PSA_FFT_CHECK(rocfft_plan_create(&p->plan, rocfft_placement_inplace, rocfft_transform_type_complex_forward,
+                                     rocfft_precision_single, 1, &len, (size_t)batch, nullptr));
+    PSA_FFT_CHECK(rocfft_plan_get_work_buffer_size(p->plan, &p->work_bytes));
+    PSA_FFT_CHECK(rocfft_execution_info_create(&p->info));
+    PSA_FFT_CHECK(rocfft_execution_info_set_stream(p->info, c->stream));
+    return PSA_OK;
+}
+
+// the primer's plan (T, 3) -- one k-vector -- joins the cache; its kernels serve every batch of that length
+static void join_primer(psa_ctx* c) {
+    if (!c->fft_primer.joinable()) return;
+    HostTimer ht(&c->oneoff_ms[0]);                    // whatever of the build is still outstanding
+    c->fft_primer.join();
+    if (c->primed.plan) {
+        auto key = std::make_pair(c->primed_T, (int64_t)3);
+        if (c->plans.find(key) == c->plans.end()) {
+            c->plans.emplace(key, c->primed);
+        } else {
+            (void)rocfft_execution_info_destroy(c->primed.info);
+            (void)rocfft_plan_destroy(c->primed.plan);
+        }
+        c->primed = FftPlan{};
+    }
+}
+
+void prime_fft(psa_ctx* c, int64_t T) {
+    if (!c->opt_fft_prime || c->fft_primer.joinable() || T < 2 || c->primed_T == T) return;
+    for (auto& kv : c->plans)
+        if (kv.first.first == T) return;
+    c->primed_T = T;
+    c->fft_primer = std::thread([c, T] {
+        (void)hipSetDevice(c->device);
+        FftPlan p;
+        if (create_plan(c, T, 3, &p) == PSA_OK) c->primed = p;
+    });
+}
+
 int get_plan(psa_ctx* c, int64_t T, int64_t batch, FftPlan** out) {
+    join_primer(c);
     auto key = std::make_pair(T, batch);
     auto it = c->plans.find(key);
     if (it == c->plans.end()) {
         HostTimer ht(&c->oneoff_ms[0]);
         FftPlan   p;
-        size_t  len = (size_t)T;
-        PSA_FFT_CHECK(rocfft_plan_create(&p.plan, rocfft_placement_inplace,
-                                         rocfft_transform_type_complex_forward,
-                                         rocfft_precision_single, 1, &len, (size_t)batch, nullptr));
-        PSA_FFT_CHECK(rocfft_plan_get_work_buffer_size(p.plan, &p.work_bytes));
-        PSA_FFT_CHECK(rocfft_execution_info_create(&p.info));
-        PSA_FFT_CHECK(rocfft_execution_info_set_stream(p.info, c->stream));
+        PSA_TRY(create_plan(c, T, batch, &p));
         it = c->plans.emplace(key, p).first;
     }
     *out = &it->second;
@@ -173,7 +211,24 @@ int psa_create(int device, psa_ctx** out) {
                 "libpsa_hip is built for gfx950 (MI355X) only; device %d is %s", device,
                 prop.gcnArchName);
     static std::once_flag fft_once;
-    std::call_once(fft_once, [] { (void)rocfft_setup(); });
+    std::call_once(fft_once, [] {
+        // rocFFT keeps run-time compiled kernels in a cache file only when it is told where: give it a
+        // per-user one (a second process then skips the compilation: 58 -> 23 ms for T = 65536,
+        // tools/fft_plan_timing.py); an explicit ROCFFT_RTC_CACHE_PATH wins
+        if (!std::getenv("ROCFFT_RTC_CACHE_PATH")) {
+            std::string dir;
+            if (const char* e = std::getenv("PSA_CACHE_DIR")) dir = e;
+            else if (const char* x = std::getenv("XDG_CACHE_HOME")) dir = std::string(x) + "/psa_amd";
+            else if (const char* h = std::getenv("HOME")) dir = std::string(h) + "/.cache/psa_amd";
+            if (!dir.empty()) {
+                std::error_code ec;
+                std::filesystem::create_directories(dir, ec);
+                if (!ec && ::access(dir.c_str(), W_OK) == 0)
+                    ::setenv("ROCFFT_RTC_CACHE_PATH", (dir + "/rocfft_rtc_cache.db").c_str(), 0);
+            }
+        }
+        (void)rocfft_setup();
+    });
     psa_ctx* c = new psa_ctx();
     c->device = device;
     c->compute_units = prop.multiProcessorCount;
@@ -193,6 +248,11 @@ int psa_destroy(psa_ctx* c) {
         Guard g(c);
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
+        if (c->fft_primer.joinable()) c->fft_primer.join();
+        if (c->primed.plan) {
+            (void)rocfft_execution_info_destroy(c->primed.info);
+            (void)rocfft_plan_destroy(c->primed.plan);
+        }
         if (c->comm) (void)ncclCommDestroy(c->comm);
         for (auto& kv : c->plans) {
             (void)rocfft_execution_info_destroy(kv.second.info);
@@ -211,7 +271,7 @@ int psa_destroy(psa_ctx* c) {
         if (c->d2h_ready) (void)hipEventDestroy(c->d2h_ready);
         for (DevBuf* b : {&c->d_kvec, &c->d_mean_all, &c->d_idx, &c->d_mean_g, &c->d_phase, &c->d_qwork,
                           &c->d_fft_work, &c->d_tables, &c->d_absmax, &c->d_slab, &c->d_out, &c->d_aux, &c->d_sync,
-                          &c->d_qrows, &c->d_stage, &c->d_bin, &c->d_upload_max})
+                          &c->d_qrows, &c->d_stage, &c->d_bin, &c->d_upload_max, &c->d_kmap, &c->d_cols, &c->d_inten})
             b->release();
         (void)hipStreamDestroy(c->stream);
     }
@@ -257,6 +317,8 @@ int psa_set_option(psa_ctx* c, int option, int64_t value) {
             PSA_REQUIRE(value >= 1, "PSA_OPT_PLANES_MIN_K must be >= 1");
             c->opt_planes_min_k = value;
             return PSA_OK;
+        case PSA_OPT_FOLD_PAIRS: c->opt_fold_pairs = value != 0; return PSA_OK;
+        case PSA_OPT_FFT_PRIME: c->opt_fft_prime = value != 0; return PSA_OK;
     }
     set_error("unknown option %d", option);
     return PSA_EINVAL;

@@ -286,7 +286,9 @@ extern "C" {
 int psa_data_alloc(psa_ctx* c, int slot, int64_t T, int64_t N) {
     PSA_TRY(enter(c));
     Guard g(c);
-    return data_alloc_locked(c, slot, T, N);
+    PSA_TRY(data_alloc_locked(c, slot, T, N));
+    prime_fft(c, T);
+    return PSA_OK;
 }
 
 int psa_data_upload(psa_ctx* c, int slot, const float* host, int64_t T, int64_t N) {
@@ -294,6 +296,7 @@ int psa_data_upload(psa_ctx* c, int slot, const float* host, int64_t T, int64_t 
     PSA_REQUIRE(host != nullptr, "null host array");
     Guard g(c);
     PSA_TRY(data_alloc_locked(c, slot, T, N));
+    prime_fft(c, T);                                   // the FFT kernels of this length compile beside the upload
     c->slot[slot].valid = false;                       // until every frame has landed
     StageTimer st(c, PSA_T_H2D);
     PSA_TRY(staged_upload(c, c->slot[slot].buf.as<float>(), host, T, N, nullptr));

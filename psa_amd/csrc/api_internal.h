@@ -12,6 +12,7 @@
 #include <cstring>
 #include <functional>
 #include <thread>
+#include <unordered_map>
 
 #include "k1_f16.h"
 
@@ -54,6 +55,7 @@ struct StageTimer {
 
 int upload(psa_ctx* c, DevBuf& b, const void* host, size_t bytes);
 int get_plan(psa_ctx* c, int64_t T, int64_t batch, FftPlan** out);
+void prime_fft(psa_ctx* c, int64_t T);               // background build of the length's kernels (api_core.hip)
 int run_fft(psa_ctx* c, float2* data, int64_t T, int64_t batch);
 int check_slot(psa_ctx* c, int slot);
 int validate_groups(int64_t N, const int32_t* group_idx, const int64_t* group_off, int32_t G);
@@ -82,6 +84,8 @@ int    launch_projection(psa_ctx* c, int slot, const int* d_idx, ProjGeom g, boo
 int    project_group(psa_ctx* c, int slot, const int* d_idx, const ProjGeom& g, bool disp, const PlaneSet* ps, float2* d_q);
 int    group_source(psa_ctx* c, int* slot_io, bool* disp_io, const float* mean_host, const int* d_idx, const int32_t* h_idx,
                     int64_t n_g, int64_t K, PlaneSet** ps);
+void   fold_pairs(const float* k, int64_t K, std::vector<int32_t>* kmap, std::vector<int32_t>* unique_idx);
+int    install_kmap(psa_ctx* c, const std::vector<int32_t>& kmap);
 int    begin_result(psa_ctx* c, int64_t T, int64_t K_total, int64_t k_offset, bool intensity, char** rows, size_t* row_bytes);
 
 }  // namespace psa

@@ -11,6 +11,79 @@ uint64_t hash_idx(const int32_t* p, int64_t n) {
     return h;
 }
 
+// Pairs (k, -k) and repeated k-vectors of a list.  kmap[i] = index into the list of vectors that are
+// actually projected (unique_idx: their positions in the input), | KMAP_MIRROR when vector i is the
+// exact negation of that one.  Exact means component-wise float equality of k_i and -k_u (so -0 == 0;
+// NaN never matches): then the float32 phase argument fma(kz,rz,fma(ky,ry,kx*rx)) is the exact negative
+// (sed_calculator.py:78 -- rounding is symmetric), cos is even and sin odd, the data are real, hence
+// q(-k) = conj q(k) and S(-k)[w] = conj S(k)[(T-w) mod T]: the partner needs no projection and no FFT
+// of its own (the reference's own heat maps are symmetric about Gamma: examples/k_grid_heatmap_example.py:33-38).
+void fold_pairs(const float* k, int64_t K, std::vector<int32_t>* kmap, std::vector<int32_t>* unique_idx) {
+    struct Key {
+        uint32_t x, y, z;
+        bool operator==(const Key& o) const { return x == o.x && y == o.y && z == o.z; }
+    };
+    struct KeyHash {
+        size_t operator()(const Key& a) const {
+            uint64_t h = 1469598103934665603ull;
+            for (uint32_t v : {a.x, a.y, a.z}) h = (h ^ v) * 1099511628211ull;
+            return (size_t)h;
+        }
+    };
+    auto bits = [](float v, bool negate) {
+        if (negate) v = -v;
+        if (v == 0.f) v = 0.f;                        // -0 and +0 are the same k
+        uint32_t u;
+        std::memcpy(&u, &v, sizeof(u));
+        return u;
+    };
+    std::unordered_map<Key, int32_t, KeyHash> seen;   // k-vector -> its row among the projected ones
+    seen.reserve((size_t)K * 2);
+    kmap->assign((size_t)K, 0);
+    unique_idx->clear();
+    for (int64_t i = 0; i < K; ++i) {
+        const float* v = k + 3 * i;
+        const bool   has_nan = v[0] != v[0] || v[1] != v[1] || v[2] != v[2];
+        const Key    same{bits(v[0], false), bits(v[1], false), bits(v[2], false)};
+        const Key    neg{bits(v[0], true), bits(v[1], true), bits(v[2], true)};
+        if (!has_nan) {
+            auto it = seen.find(same);
+            if (it != seen.end()) {
+                (*kmap)[i] = it->second;
+                continue;
+            }
+            it = seen.find(neg);
+            if (it != seen.end()) {
+                (*kmap)[i] = it->second | KMAP_MIRROR;
+                continue;
+            }
+        }
+        const int32_t row = (int32_t)unique_idx->size();
+        unique_idx->push_back((int32_t)i);
+        (*kmap)[i] = row;
+        if (!has_nan) seen.emplace(same, row);
+    }
+}
+
+// the list the projection runs on when folding pays: *uniq_k receives the unique vectors and the k map
+// is left in c->kmap (installed by install_kmap after begin_result); false = project the list as it is
+static bool fold_k_list(psa_ctx* c, const float* k, int64_t K, std::vector<float>* uniq_k, std::vector<int32_t>* kmap) {
+    if (!c->opt_fold_pairs || K < 2 || K >= (1ll << 30)) return false;
+    std::vector<int32_t> uidx;
+    fold_pairs(k, K, kmap, &uidx);
+    if ((int64_t)uidx.size() == K) return false;
+    uniq_k->resize(uidx.size() * 3);
+    for (size_t u = 0; u < uidx.size(); ++u) std::memcpy(uniq_k->data() + 3 * u, k + 3 * (size_t)uidx[u], 3 * sizeof(float));
+    return true;
+}
+
+int install_kmap(psa_ctx* c, const std::vector<int32_t>& kmap) {
+    c->kmap = kmap;
+    c->out_K = (int64_t)kmap.size();
+    c->out_valid = false;
+    return upload(c, c->d_kmap, c->kmap.data(), c->kmap.size() * sizeof(int32_t));
+}
+
 size_t planes_bytes_held(psa_ctx* c) {
     size_t b = 0;
     for (auto& ps : c->planes) b += ps->buf.cap;
@@ -282,6 +355,9 @@ int begin_result(psa_ctx* c, int64_t T, int64_t K_total, int64_t k_offset, bool 
     c->res_intensity = intensity;
     c->slab_valid = true;
     c->out_valid = false;
+    c->inten_valid = false;
+    c->kmap.clear();
+    c->out_K = K_total;
     c->plane_call_mark = c->plane_tick + 1;
     *rows = (char*)c->d_slab.ptr + *row_bytes * (size_t)k_offset;
     return PSA_OK;
@@ -350,14 +426,23 @@ int psa_sed_project(psa_ctx* c, int slot, const float* mean_pos_all, const float
     PSA_TRY(enter(c));
     Guard guard(c);
     PSA_TRY(check_slot(c, slot));
-    const ProjectArgs a{slot, mean_pos_all, k_vectors, K_local, K_total, k_offset, group_idx, group_off, G, flags};
-    const int64_t     T = c->slot[slot].T, N = c->slot[slot].N;
-    const bool        intensity = (flags & PSA_F_INTENSITY) != 0;
-    bool              disp = (flags & PSA_F_DISPLACEMENTS) != 0;
+    ProjectArgs   a{slot, mean_pos_all, k_vectors, K_local, K_total, k_offset, group_idx, group_off, G, flags};
+    const int64_t T = c->slot[slot].T, N = c->slot[slot].N;
+    const bool    intensity = (flags & PSA_F_INTENSITY) != 0;
+    bool          disp = (flags & PSA_F_DISPLACEMENTS) != 0;
     PSA_TRY(check_project_args(c, a, N));
+    // the whole list on this device: k-vectors whose negation (or twin) is in the list are not projected
+    std::vector<float>   uniq_k;
+    std::vector<int32_t> kmap;
+    const bool folded = K_local == K_total && k_offset == 0 && fold_k_list(c, k_vectors, K_local, &uniq_k, &kmap);
+    if (folded) {
+        a.k_vectors = uniq_k.data();
+        a.K_local = a.K_total = K_local = K_total = (int64_t)uniq_k.size() / 3;
+    }
     char*  rows = nullptr;
     size_t row_bytes = 0;
     PSA_TRY(begin_result(c, T, K_total, k_offset, intensity, &rows, &row_bytes));
+    if (folded) PSA_TRY(install_kmap(c, kmap));
     if (K_local == 0) return PSA_OK;
     PSA_TRY(upload_project_inputs(c, a, N));
 
@@ -382,7 +467,14 @@ int psa_sed_project_upload(psa_ctx* c, int slot, const float* host, int64_t T, i
     PSA_TRY(enter(c));
     PSA_REQUIRE(host != nullptr, "null host array");
     PSA_REQUIRE(K >= 1, "need at least one k-vector");
-    Guard             guard(c);
+    Guard                guard(c);
+    std::vector<float>   uniq_k;
+    std::vector<int32_t> kmap;
+    const bool           folded = k_vectors != nullptr && fold_k_list(c, k_vectors, K, &uniq_k, &kmap);
+    if (folded) {
+        k_vectors = uniq_k.data();
+        K = (int64_t)uniq_k.size() / 3;
+    }
     const ProjectArgs a{slot, mean_pos_all, k_vectors, K, K, 0, group_idx, group_off, G, flags};
     PSA_REQUIRE(slot >= 0 && slot < PSA_NUM_SLOTS, "bad data slot %d", slot);
     PSA_REQUIRE(T > 0 && N > 0, "empty trajectory (T=%lld, N=%lld)", (long long)T, (long long)N);
@@ -394,6 +486,7 @@ int psa_sed_project_upload(psa_ctx* c, int slot, const float* host, int64_t T, i
     char*      rows = nullptr;
     size_t     row_bytes = 0;
     PSA_TRY(begin_result(c, T, K, 0, intensity, &rows, &row_bytes));
+    if (folded) PSA_TRY(install_kmap(c, kmap));
     PSA_TRY(upload_project_inputs(c, a, N));
     float2* d_q = intensity ? nullptr : (float2*)rows;
     if (intensity) {
@@ -482,34 +575,56 @@ int psa_sed_project_upload(psa_ctx* c, int slot, const float* host, int64_t T, i
     return PSA_OK;
 }
 
-static size_t result_bytes(const psa_ctx* c) {
-    return c->res_intensity ? (size_t)c->res_T * c->res_K * sizeof(float) : (size_t)c->res_T * c->res_K * 3 * sizeof(float2);
+static int64_t result_K(const psa_ctx* c) { return c->kmap.empty() ? c->res_K : c->out_K; }
+static size_t  result_bytes(const psa_ctx* c) {
+    return c->res_intensity ? (size_t)c->res_T * result_K(c) * sizeof(float) : (size_t)c->res_T * result_K(c) * 3 * sizeof(float2);
+}
+static size_t intensity_bytes(const psa_ctx* c) { return (size_t)c->res_T * result_K(c) * sizeof(float); }
+
+static int check_result_buffers(const psa_ctx* c, const void* out_host, size_t out_bytes, const float* out_intensity,
+                                size_t out_intensity_bytes) {
+    const size_t bytes = result_bytes(c);
+    PSA_REQUIRE(out_host == nullptr || out_bytes == bytes,
+                "result is %zu bytes (T=%lld, K=%lld, %s), the caller's buffer %zu", bytes, (long long)c->res_T,
+                (long long)result_K(c), c->res_intensity ? "float32 intensity" : "complex64 x 3", out_bytes);
+    PSA_REQUIRE(out_intensity == nullptr || !c->res_intensity,
+                "out_intensity goes with a complex result; an intensity result IS out_host");
+    PSA_REQUIRE(out_intensity == nullptr || out_intensity_bytes == intensity_bytes(c),
+                "intensity is (%lld,%lld) float32 = %zu bytes, the caller's buffer %zu", (long long)c->res_T,
+                (long long)result_K(c), intensity_bytes(c), out_intensity_bytes);
+    return PSA_OK;
 }
 
-int psa_sed_finalize(psa_ctx* c, void* out_host, size_t out_bytes) {
+int psa_sed_finalize(psa_ctx* c, void* out_host, size_t out_bytes, float* out_intensity, size_t out_intensity_bytes) {
     PSA_TRY(enter(c));
     Guard guard(c);
     if (!c->slab_valid) {
         set_error("psa_sed_finalize before psa_sed_project");
         return PSA_ESTATE;
     }
-    const int64_t T = c->res_T, K = c->res_K;
+    const int64_t T = c->res_T, K = result_K(c);
     const size_t  bytes = result_bytes(c);
-    PSA_REQUIRE(out_host == nullptr || out_bytes == bytes,
-                "result is %zu bytes (T=%lld, K=%lld, %s), the caller's buffer %zu", bytes, (long long)T, (long long)K,
-                c->res_intensity ? "float32 intensity" : "complex64 x 3", out_bytes);
+    PSA_TRY(check_result_buffers(c, out_host, out_bytes, out_intensity, out_intensity_bytes));
     PSA_TRY(c->d_out.reserve(bytes));
+    const int32_t* d_map = c->kmap.empty() ? nullptr : c->d_kmap.as<int32_t>();
     {
         StageTimer st(c, PSA_T_TRANSPOSE);
-        if (c->res_intensity)
-            PSA_TRY(launch_transpose_f32(c, c->d_slab.as<float>(), c->d_out.as<float>(), T, K));
-        else
-            PSA_TRY(launch_scale_transpose_c64(c, c->d_slab.as<float2>(), c->d_out.as<float2>(), T, K, K, 0));
+        if (c->res_intensity) {
+            PSA_TRY(launch_transpose_f32(c, c->d_slab.as<float>(), c->d_out.as<float>(), T, K, d_map));
+        } else {
+            // SED.intensity (core/sed.py:22-24) comes out of the same pass over the result
+            PSA_TRY(c->d_inten.reserve(intensity_bytes(c)));
+            PSA_TRY(launch_scale_transpose_c64(c, c->d_slab.as<float2>(), c->d_out.as<float2>(), c->d_inten.as<float>(), T, K, K,
+                                               0, 0, nullptr, d_map));
+            c->inten_valid = true;
+        }
     }
     c->out_valid = true;
-    if (out_host) {
+    if (out_host || out_intensity) {
         StageTimer st(c, PSA_T_D2H);
-        PSA_HIP_CHECK(hipMemcpyAsync(out_host, c->d_out.ptr, bytes, hipMemcpyDeviceToHost, c->stream));
+        if (out_host) PSA_HIP_CHECK(hipMemcpyAsync(out_host, c->d_out.ptr, bytes, hipMemcpyDeviceToHost, c->stream));
+        if (out_intensity)
+            PSA_HIP_CHECK(hipMemcpyAsync(out_intensity, c->d_inten.ptr, intensity_bytes(c), hipMemcpyDeviceToHost, c->stream));
         PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     return PSA_OK;
@@ -523,11 +638,27 @@ int psa_sed_finalize(psa_ctx* c, void* out_host, size_t out_bytes) {
 //   r >= 1 (copy-bound, e.g. the 2500-point grid on 8192 atoms): what stays exposed is the FIRST
 //          block's projection -> a first block of 128, then blocks of 512.
 // Lists shorter than 192 are not split (every block is at least one M block of 64).
-static std::vector<int64_t> pipeline_blocks(int64_t K, int64_t n_g) {
+// K_rows: k-vectors projected; K_out >= K_rows: columns of the result (folded pairs copy twice the
+// columns per projected vector, which moves r up).
+static std::vector<int64_t> pipeline_blocks(int64_t K_rows, int64_t K_out, int64_t n_g) {
     std::vector<int64_t> b;
+    const int64_t        K = K_rows;
+    const double         r = 1.9e4 / (double)std::max<int64_t>(n_g, 1) * (double)K_out / (double)std::max<int64_t>(K_rows, 1);
+    if (const char* e = std::getenv("PSA_PIPELINE_BLOCKS")) {       // experiments: "192,64"
+        int64_t left = K;
+        for (const char* q = e; *q && left > 0;) {
+            const int64_t n = std::min<int64_t>(std::max<int64_t>(1, std::atoll(q)), left);
+            b.push_back(n);
+            left -= n;
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+        if (left > 0) b.push_back(left);
+        return b;
+    }
     if (K < 192) {
         b.push_back(K);
-    } else if (1.9e4 / (double)std::max<int64_t>(n_g, 1) < 1.0) {
+    } else if (r < 1.0) {
         b.push_back(K - 64);
         b.push_back(64);
     } else {
@@ -541,21 +672,70 @@ static std::vector<int64_t> pipeline_blocks(int64_t K, int64_t n_g) {
     return b;
 }
 
+// PSA_TIMELINE=1: where a pipelined calculate spends its time -- events on both streams, printed
+// (ms since entry) to stderr when the call returns.  Diagnostics only (tools/e2e_timeline.py).
+struct Timeline {
+    bool on = std::getenv("PSA_TIMELINE") != nullptr;
+    std::chrono::steady_clock::time_point t_host0 = std::chrono::steady_clock::now();
+    hipEvent_t   e0 = nullptr;
+    struct Mark { const char* what; int block; hipEvent_t ev; double host_ms; };
+    std::vector<Mark> marks;
+    double host_ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(); }
+    void start(hipStream_t s) {
+        if (!on) return;
+        (void)hipEventCreate(&e0);
+        (void)hipEventRecord(e0, s);
+    }
+    void mark(const char* what, int block, hipStream_t s) {
+        if (!on) return;
+        hipEvent_t ev = nullptr;
+        (void)hipEventCreate(&ev);
+        (void)hipEventRecord(ev, s);
+        marks.push_back({what, block, ev, host_ms()});
+    }
+    void report() {
+        if (!on) return;
+        const double t_end = host_ms();
+        std::fprintf(stderr, "[psa timeline] %-22s %5s %10s %10s\n", "event", "block", "device_ms", "issued_ms");
+        for (auto& m : marks) {
+            float ms = -1.f;
+            (void)hipEventElapsedTime(&ms, e0, m.ev);
+            std::fprintf(stderr, "[psa timeline] %-22s %5d %10.3f %10.3f\n", m.what, m.block, ms, m.host_ms);
+            (void)hipEventDestroy(m.ev);
+        }
+        std::fprintf(stderr, "[psa timeline] %-22s %5s %10s %10.3f\n", "return", "", "", t_end);
+        if (e0) (void)hipEventDestroy(e0);
+    }
+};
+
 // Complex result of one group, all K on this device, straight to the host: per block of k-vectors
-// project -> FFT -> scale/transpose into its columns of (T, K, 3) -> 2-D D2H on a copy stream
-// (full PCIe rate at >= 1.5-KB rows: tools/probes/d2h_2d.hip), overlapped with the next block.
-static int calculate_pipelined(psa_ctx* c, const ProjectArgs& a, void* out_host) {
-    int       slot = a.slot;
-    const int64_t K = a.K_total;
+// project -> FFT -> scale/transpose (+ intensity) into its columns of (T, K, 3) -> 2-D D2H on a copy
+// stream (full PCIe rate at >= 1.5-KB rows: tools/probes/d2h_2d.hip), overlapped with the next block.
+// Folded lists: a block's columns are its own k-vectors' and their partners' (for a grid symmetric
+// about Gamma: two runs of columns per block).
+static int calculate_pipelined(psa_ctx* c, const ProjectArgs& a_in, void* out_host, float* out_intensity) {
+    int           slot = a_in.slot;
+    ProjectArgs   a = a_in;
+    const int64_t K_out = a.K_total;
     PSA_TRY(check_slot(c, slot));
     const int64_t T = c->slot[slot].T, N = c->slot[slot].N;
     bool          disp = (a.flags & PSA_F_DISPLACEMENTS) != 0;
     PSA_TRY(check_project_args(c, a, N));
+    std::vector<float>   uniq_k;
+    std::vector<int32_t> kmap;
+    const bool           folded = fold_k_list(c, a.k_vectors, K_out, &uniq_k, &kmap);
+    if (folded) {
+        a.k_vectors = uniq_k.data();
+        a.K_local = a.K_total = (int64_t)uniq_k.size() / 3;
+    }
+    const int64_t K = a.K_total;                                   // rows of the slab
     char*  rows = nullptr;
     size_t row_bytes = 0;
     PSA_TRY(begin_result(c, T, K, 0, false, &rows, &row_bytes));
+    if (folded) PSA_TRY(install_kmap(c, kmap));
     PSA_TRY(upload_project_inputs(c, a, N));
     PSA_TRY(c->d_out.reserve(result_bytes(c)));
+    PSA_TRY(c->d_inten.reserve(intensity_bytes(c)));
     if (!c->d2h_stream) PSA_HIP_CHECK(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
     if (!c->d2h_ready) PSA_HIP_CHECK(hipEventCreateWithFlags(&c->d2h_ready, hipEventDisableTiming));
     const int64_t  n_g = a.group_idx ? (a.group_off[1] - a.group_off[0]) : N;
@@ -563,58 +743,163 @@ static int calculate_pipelined(psa_ctx* c, const ProjectArgs& a, void* out_host)
     const int32_t* h_idx = a.group_idx ? a.group_idx : nullptr;
     if (n_g == 0) {
         std::memset(out_host, 0, result_bytes(c));
+        if (out_intensity) std::memset(out_intensity, 0, intensity_bytes(c));
         PSA_HIP_CHECK(hipMemsetAsync(c->d_out.ptr, 0, result_bytes(c), c->stream));
+        PSA_HIP_CHECK(hipMemsetAsync(c->d_inten.ptr, 0, intensity_bytes(c), c->stream));
         PSA_HIP_CHECK(hipMemsetAsync(rows, 0, row_bytes * (size_t)K, c->stream));
-        c->out_valid = true;
+        c->out_valid = c->inten_valid = true;
         return PSA_OK;
+    }
+    const std::vector<int64_t> blocks = pipeline_blocks(K, K_out, n_g);
+    // columns of every block, ascending within a block: cols / srcs, block b at [first[b], first[b+1])
+    std::vector<int32_t> cols, srcs;
+    std::vector<size_t>  first(blocks.size() + 1, 0);
+    bool                 copy_by_block = true;
+    if (folded) {
+        std::vector<int> block_of((size_t)K);
+        {
+            int64_t r0 = 0;
+            for (size_t b = 0; b < blocks.size(); r0 += blocks[b], ++b)
+                for (int64_t r = r0; r < r0 + blocks[b]; ++r) block_of[(size_t)r] = (int)b;
+        }
+        for (int64_t k = 0; k < K_out; ++k) ++first[(size_t)block_of[(size_t)(kmap[k] & ~KMAP_MIRROR)] + 1];
+        for (size_t b = 0; b < blocks.size(); ++b) first[b + 1] += first[b];
+        cols.resize((size_t)K_out);
+        srcs.resize((size_t)K_out);
+        std::vector<size_t> at(first.begin(), first.end() - 1);
+        for (int64_t k = 0; k < K_out; ++k) {
+            const size_t i = at[(size_t)block_of[(size_t)(kmap[k] & ~KMAP_MIRROR)]]++;
+            cols[i] = (int32_t)k;
+            srcs[i] = kmap[k];
+        }
+        for (size_t b = 0; b < blocks.size() && copy_by_block; ++b) {   // more than a few runs of columns: one copy at the end
+            int runs = 0;
+            for (size_t i = first[b]; i < first[b + 1]; ++i) runs += i == first[b] || cols[i] != cols[i - 1] + 1;
+            copy_by_block = runs <= 8;
+        }
+        PSA_TRY(c->d_cols.reserve((size_t)2 * K_out * sizeof(int32_t)));
+        PSA_HIP_CHECK(hipMemcpyAsync(c->d_cols.ptr, cols.data(), (size_t)K_out * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        PSA_HIP_CHECK(hipMemcpyAsync(c->d_cols.as<int32_t>() + K_out, srcs.data(), (size_t)K_out * sizeof(int32_t),
+                                     hipMemcpyHostToDevice, c->stream));
     }
     PlaneSet* ps = nullptr;
     PSA_TRY(group_source(c, &slot, &disp, a.mean_pos_all, d_idx, h_idx, n_g, K, &ps));
-    const size_t pitch = (size_t)K * 3 * sizeof(float2);
-    int64_t      k0 = 0;
-    for (const int64_t nk : pipeline_blocks(K, n_g)) {
-        float2* d_q = (float2*)(rows + row_bytes * (size_t)k0);
+    Timeline tl;
+    tl.start(c->stream);
+    const size_t pitch = (size_t)K_out * 3 * sizeof(float2);
+    auto copy_columns = [&](int64_t col0, int64_t n) -> int {
+        const size_t off = (size_t)col0 * 3 * sizeof(float2), width = (size_t)n * 3 * sizeof(float2);
+        PSA_HIP_CHECK(hipMemcpy2DAsync((char*)out_host + off, pitch, (const char*)c->d_out.ptr + off, pitch, width, (size_t)T,
+                                       hipMemcpyDeviceToHost, c->d2h_stream));
+        return PSA_OK;
+    };
+    int64_t k0 = 0;
+    for (size_t b = 0; b < blocks.size(); ++b) {
+        const int64_t nk = blocks[b];
+        float2*       d_q = (float2*)(rows + row_bytes * (size_t)k0);
         ProjGeom      g;
         PSA_TRY(make_geom(c, slot, nk, n_g, d_idx, h_idx, disp, ps, 0, &g));
         PSA_TRY(prepare_phase(c, d_idx, g, disp, k0));
         PSA_TRY(launch_projection(c, slot, d_idx, g, disp, ps, d_q, T, 0, T));
+        tl.mark("projected", (int)b, c->stream);
         {
             StageTimer st(c, PSA_T_FFT);
             PSA_TRY(run_fft(c, d_q, T, 3 * nk));
         }
+        tl.mark("fft done", (int)b, c->stream);
         {
             StageTimer st(c, PSA_T_TRANSPOSE);
-            PSA_TRY(launch_scale_transpose_c64(c, d_q, c->d_out.as<float2>(), T, nk, K, k0));
+            if (folded)
+                PSA_TRY(launch_scale_transpose_c64(c, (const float2*)rows, c->d_out.as<float2>(), c->d_inten.as<float>(), T,
+                                                   (int64_t)(first[b + 1] - first[b]), K_out, 0, 0,
+                                                   c->d_cols.as<int32_t>() + first[b], c->d_cols.as<int32_t>() + K_out + first[b]));
+            else
+                PSA_TRY(launch_scale_transpose_c64(c, (const float2*)rows, c->d_out.as<float2>(), c->d_inten.as<float>(), T, nk,
+                                                   K_out, k0, k0, nullptr, nullptr));
         }
-        PSA_HIP_CHECK(hipEventRecord(c->d2h_ready, c->stream));
-        PSA_HIP_CHECK(hipStreamWaitEvent(c->d2h_stream, c->d2h_ready, 0));
-        const size_t off = (size_t)k0 * 3 * sizeof(float2), width = (size_t)nk * 3 * sizeof(float2);
-        PSA_HIP_CHECK(hipMemcpy2DAsync((char*)out_host + off, pitch, (const char*)c->d_out.ptr + off, pitch, width, (size_t)T,
-                                       hipMemcpyDeviceToHost, c->d2h_stream));
+        tl.mark("transposed", (int)b, c->stream);
+        if (copy_by_block) {
+            PSA_HIP_CHECK(hipEventRecord(c->d2h_ready, c->stream));
+            PSA_HIP_CHECK(hipStreamWaitEvent(c->d2h_stream, c->d2h_ready, 0));
+            tl.mark("copy can start", (int)b, c->d2h_stream);
+            if (!folded) {
+                PSA_TRY(copy_columns(k0, nk));
+            } else {
+                for (size_t i = first[b]; i < first[b + 1];) {
+                    size_t j = i + 1;
+                    while (j < first[b + 1] && cols[j] == cols[j - 1] + 1) ++j;
+                    PSA_TRY(copy_columns(cols[i], (int64_t)(j - i)));
+                    i = j;
+                }
+            }
+            tl.mark("copied", (int)b, c->d2h_stream);
+        }
         k0 += nk;
     }
-    c->out_valid = true;
+    c->out_valid = c->inten_valid = true;
+    if (!copy_by_block || out_intensity) {
+        PSA_HIP_CHECK(hipEventRecord(c->d2h_ready, c->stream));
+        PSA_HIP_CHECK(hipStreamWaitEvent(c->d2h_stream, c->d2h_ready, 0));
+        if (!copy_by_block)
+            PSA_HIP_CHECK(hipMemcpyAsync(out_host, c->d_out.ptr, result_bytes(c), hipMemcpyDeviceToHost, c->d2h_stream));
+        if (out_intensity)
+            PSA_HIP_CHECK(hipMemcpyAsync(out_intensity, c->d_inten.ptr, intensity_bytes(c), hipMemcpyDeviceToHost, c->d2h_stream));
+        tl.mark("intensity copied", -1, c->d2h_stream);
+    }
     PSA_HIP_CHECK(hipStreamSynchronize(c->d2h_stream));
     PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    tl.report();
     return PSA_OK;
 }
 
 int psa_sed_calculate(psa_ctx* c, int slot, const float* mean_pos_all, const float* k_vectors,
                       int64_t K, const int32_t* group_idx, const int64_t* group_off, int32_t G,
-                      int32_t flags, void* out_host, size_t out_bytes) {
+                      int32_t flags, void* out_host, size_t out_bytes, float* out_intensity, size_t out_intensity_bytes) {
     PSA_REQUIRE(K >= 1, "need at least one k-vector");
+    PSA_REQUIRE(out_intensity == nullptr || !(flags & PSA_F_INTENSITY),
+                "out_intensity goes with a complex result; an intensity result IS out_host");
     if (out_host && !(flags & PSA_F_INTENSITY) && G == 1 && K >= 192 && c && c->k1_selector == PSA_K1_AUTO) {
         PSA_TRY(enter(c));
         Guard guard(c);
         PSA_TRY(check_slot(c, slot));
         const size_t bytes = (size_t)c->slot[slot].T * K * 3 * sizeof(float2);
+        PSA_REQUIRE(k_vectors != nullptr, "null k_vectors");
         PSA_REQUIRE(out_bytes == bytes, "result is %zu bytes (T=%lld, K=%lld, complex64 x 3), the caller's buffer %zu", bytes,
                     (long long)c->slot[slot].T, (long long)K, out_bytes);
+        PSA_REQUIRE(out_intensity == nullptr || out_intensity_bytes == bytes / 6,
+                    "intensity is (%lld,%lld) float32 = %zu bytes, the caller's buffer %zu", (long long)c->slot[slot].T,
+                    (long long)K, bytes / 6, out_intensity_bytes);
         const ProjectArgs a{slot, mean_pos_all, k_vectors, K, K, 0, group_idx, group_off, G, flags};
-        return calculate_pipelined(c, a, out_host);
+        return calculate_pipelined(c, a, out_host, out_intensity);
     }
     PSA_TRY(psa_sed_project(c, slot, mean_pos_all, k_vectors, K, K, 0, group_idx, group_off, G, flags));
-    return psa_sed_finalize(c, out_host, out_bytes);
+    return psa_sed_finalize(c, out_host, out_bytes, out_intensity, out_intensity_bytes);
+}
+
+// The k map of a result whose rows were projected from a folded list by the caller (a sharded run:
+// psa_amd/dist.py folds, shards the unique vectors, and installs the map on the ranks that finalize).
+int psa_sed_set_kmap(psa_ctx* c, const int32_t* kmap, int64_t K_out) {
+    PSA_TRY(enter(c));
+    Guard guard(c);
+    if (!c->slab_valid) {
+        set_error("psa_sed_set_kmap before psa_sed_project");
+        return PSA_ESTATE;
+    }
+    PSA_REQUIRE(K_out >= 0 && K_out < (1ll << 30) && (kmap != nullptr || K_out == 0), "bad k map");
+    for (int64_t k = 0; k < K_out; ++k)
+        PSA_REQUIRE((int64_t)(kmap[k] & ~KMAP_MIRROR) < c->res_K, "k map entry %lld points past the slab's %lld rows",
+                    (long long)k, (long long)c->res_K);
+    return install_kmap(c, std::vector<int32_t>(kmap, kmap + K_out));
+}
+
+int psa_k_pairs(const float* k_vectors, int64_t K, int32_t* kmap, int32_t* unique_idx, int64_t* n_unique) {
+    PSA_REQUIRE(K >= 0 && K < (1ll << 30) && (K == 0 || (k_vectors && kmap && unique_idx)) && n_unique, "bad argument");
+    std::vector<int32_t> m, u;
+    fold_pairs(k_vectors, K, &m, &u);
+    if (K) std::memcpy(kmap, m.data(), (size_t)K * sizeof(int32_t));
+    if (!u.empty()) std::memcpy(unique_idx, u.data(), u.size() * sizeof(int32_t));
+    *n_unique = (int64_t)u.size();
+    return PSA_OK;
 }
 
 // one (k, omega) bin of one group: K = 1 projection + one DFT dot (psa_hip.h)
@@ -696,7 +981,7 @@ int psa_slab_write(psa_ctx* c, int64_t row0, int64_t nrows, const void* host) {
         PSA_HIP_CHECK(hipMemcpyAsync((char*)c->d_slab.ptr + off, host, bytes, hipMemcpyHostToDevice,
                                      c->stream));
     PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
-    c->out_valid = false;
+    c->out_valid = c->inten_valid = false;
     return PSA_OK;
 }
 
@@ -707,17 +992,18 @@ int psa_result_intensity(psa_ctx* c, float* out_host, size_t out_bytes) {
         set_error("psa_result_intensity needs a finalized complex result");
         return PSA_ESTATE;
     }
-    const int64_t n = c->res_T * c->res_K;
+    const int64_t n = c->res_T * result_K(c);
     PSA_REQUIRE(out_host == nullptr || out_bytes == (size_t)n * sizeof(float),
                 "result is (%lld,%lld) float32 = %zu bytes, the caller's buffer %zu", (long long)c->res_T,
-                (long long)c->res_K, (size_t)n * sizeof(float), out_bytes);
-    PSA_TRY(c->d_aux.reserve((size_t)n * sizeof(float)));
-    {
+                (long long)result_K(c), (size_t)n * sizeof(float), out_bytes);
+    if (!c->inten_valid) {                      // (finalize and calculate leave it behind; kept for results placed otherwise)
+        PSA_TRY(c->d_inten.reserve((size_t)n * sizeof(float)));
         StageTimer st(c, PSA_T_EPILOGUE);
-        PSA_TRY(launch_result_intensity(c, c->d_out.as<float2>(), c->d_aux.as<float>(), n));
+        PSA_TRY(launch_result_intensity(c, c->d_out.as<float2>(), c->d_inten.as<float>(), n));
+        c->inten_valid = true;
     }
     if (out_host) {
-        PSA_HIP_CHECK(hipMemcpyAsync(out_host, c->d_aux.ptr, (size_t)n * sizeof(float),
+        PSA_HIP_CHECK(hipMemcpyAsync(out_host, c->d_inten.ptr, (size_t)n * sizeof(float),
                                      hipMemcpyDeviceToHost, c->stream));
         PSA_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
@@ -732,10 +1018,10 @@ int psa_result_chiral_phase(psa_ctx* c, int c1, int c2, float* out_host, size_t 
         return PSA_ESTATE;
     }
     PSA_REQUIRE(c1 >= 0 && c1 < 3 && c2 >= 0 && c2 < 3, "component indices must be 0..2");
-    const int64_t n = c->res_T * c->res_K;
+    const int64_t n = c->res_T * result_K(c);
     PSA_REQUIRE(out_host == nullptr || out_bytes == (size_t)n * sizeof(float),
                 "result is (%lld,%lld) float32 = %zu bytes, the caller's buffer %zu", (long long)c->res_T,
-                (long long)c->res_K, (size_t)n * sizeof(float), out_bytes);
+                (long long)result_K(c), (size_t)n * sizeof(float), out_bytes);
     PSA_TRY(c->d_aux.reserve((size_t)n * sizeof(float)));
     PSA_TRY(launch_result_chiral_c(c, c->d_out.as<float2>(), c->d_aux.as<float>(), n, c1, c2));
     if (out_host) {

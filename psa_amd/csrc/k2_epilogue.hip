@@ -15,45 +15,85 @@ namespace psa {
 constexpr int TT = 64;   // frames per tile
 constexpr int KT = 16;   // k-points per tile
 
+// Column maps (psa_ctx.h: KMAP_MIRROR).  Entry i of a launch writes output column cols[i] (null:
+// col_first + i) from slab row srcs[i] & ~KMAP_MIRROR (null: src_first + i).  With KMAP_MIRROR set the
+// column is the partner -k of the k-vector that row was projected for: S(-k)[w] = conj S(k)[(T-w) mod T]
+// (the float32 phase argument is odd in k, cos even, sin odd, the data real: q(-k) = conj q(k) bit for
+// bit), so the row is read backwards in frequency and conjugated instead of being projected and
+// transformed a second time.
+__device__ __forceinline__ int64_t mirrored_frame(int64_t t, int64_t T) { return t == 0 ? 0 : T - t; }
+
+// S[k,c,w]/T -> out[w,col,c]; inten (may be null): sum_c |out[w,col,c]|^2 -> inten[w,col], taken from
+// the tile while it is in LDS (core/sed.py:22-24 without a second pass over the result)
 __global__ void __launch_bounds__(256)
-scale_transpose_c64_kernel(const float2* __restrict__ slab, float2* __restrict__ out, int64_t T,
-                           int64_t K, int64_t K_pitch, int64_t k_first) {
-    // slab: rows of the K k-vectors [k_first, k_first + K) of a result with K_pitch k-vectors
+scale_transpose_c64_kernel(const float2* __restrict__ slab, float2* __restrict__ out, float* __restrict__ inten, int64_t T,
+                           int64_t n, int64_t K_pitch, int64_t col_first, int64_t src_first, const int32_t* __restrict__ cols,
+                           const int32_t* __restrict__ srcs) {
     __shared__ float2 tile[KT * 3][TT + 1];
+    __shared__ int    col_s[KT], src_s[KT];
     const int64_t t0 = (int64_t)blockIdx.x * TT;
-    const int64_t k0 = (int64_t)blockIdx.y * KT;
+    const int64_t i0 = (int64_t)blockIdx.y * KT;
     const int     tid = threadIdx.x;
     const float   n_t = (float)T;
+    if (tid < KT) {
+        const int64_t i = i0 + tid;
+        col_s[tid] = i < n ? (cols ? cols[i] : (int)(col_first + i)) : -1;
+        src_s[tid] = i < n ? (srcs ? srcs[i] : (int)(src_first + i)) : 0;
+    }
+    __syncthreads();
     {
-        const int tl = tid & 63;
+        const int     tl = tid & 63;
+        const int64_t t = t0 + tl;
 #pragma unroll
         for (int j = 0; j < KT * 3 / 4; ++j) {
-            const int     r = (tid >> 6) + 4 * j;      // row = k_local*3 + c
-            const int64_t k = k0 + r / 3;
-            float2 v = make_float2(0.f, 0.f);
-            if (k < K && t0 + tl < T) {
-                v = slab[(k * 3 + r % 3) * T + t0 + tl];
+            const int r = (tid >> 6) + 4 * j;      // row = entry*3 + c
+            const int e = r / 3;
+            float2    v = make_float2(0.f, 0.f);
+            if (col_s[e] >= 0 && t < T) {
+                const int     src = src_s[e];
+                const bool    mirror = (src & KMAP_MIRROR) != 0;
+                const int64_t row = src & ~KMAP_MIRROR;
+                v = slab[(row * 3 + r % 3) * T + (mirror ? mirrored_frame(t, T) : t)];
                 // complex64 / int in NumPy is a true division of both parts (:83)
                 v.x = __fdiv_rn(v.x, n_t);
                 v.y = __fdiv_rn(v.y, n_t);
+                if (mirror) v.y = -v.y;
             }
             tile[r][tl] = v;
         }
     }
     __syncthreads();
-    const int kn = (int)((K - k0) < KT ? (K - k0) : KT) * 3;   // valid elements per frame row
     for (int item = tid; item < TT * KT * 3; item += 256) {
         const int tl = item / (KT * 3), e = item - tl * (KT * 3);
-        if (e < kn && t0 + tl < T) out[((t0 + tl) * K_pitch + k_first + k0) * 3 + e] = tile[e][tl];
+        const int col = col_s[e / 3];
+        if (col >= 0 && t0 + tl < T) out[((t0 + tl) * K_pitch + col) * 3 + e % 3] = tile[e][tl];
+    }
+    if (inten) {
+        for (int item = tid; item < TT * KT; item += 256) {
+            const int tl = item / KT, e = item - tl * KT;
+            const int col = col_s[e];
+            if (col >= 0 && t0 + tl < T) {
+                float s = 0.f;
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    const float2 v = tile[e * 3 + cc][tl];
+                    s += v.x * v.x + v.y * v.y;
+                }
+                inten[(t0 + tl) * K_pitch + col] = s;
+            }
+        }
     }
 }
 
-int launch_scale_transpose_c64(psa_ctx* c, const float2* d_slab, float2* d_out, int64_t T, int64_t K, int64_t K_pitch,
-                               int64_t k_first) {
-    const int64_t gy = (K + KT - 1) / KT;
+int launch_scale_transpose_c64(psa_ctx* c, const float2* d_slab, float2* d_out, float* d_inten, int64_t T, int64_t n,
+                               int64_t K_pitch, int64_t col_first, int64_t src_first, const int32_t* d_cols,
+                               const int32_t* d_srcs) {
+    if (n == 0) return PSA_OK;
+    const int64_t gy = (n + KT - 1) / KT;
     PSA_REQUIRE(gy <= 65535, "too many k-points for one transpose launch");
     dim3 grid((unsigned)((T + TT - 1) / TT), (unsigned)gy);
-    hipLaunchKernelGGL(scale_transpose_c64_kernel, grid, dim3(256), 0, c->stream, d_slab, d_out, T, K, K_pitch, k_first);
+    hipLaunchKernelGGL(scale_transpose_c64_kernel, grid, dim3(256), 0, c->stream, d_slab, d_out, d_inten, T, n, K_pitch,
+                       col_first, src_first, d_cols, d_srcs);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
 }
@@ -88,15 +128,23 @@ int launch_intensity_accumulate(psa_ctx* c, const float2* d_q, float* d_slab_row
     return PSA_OK;
 }
 
+// I[row,w] -> out[w,k]; srcs (may be null: row = k) as above -- a mirrored column reads its partner's
+// row backwards in frequency: I(-k)[w] = I(k)[(T-w) mod T]
 __global__ void __launch_bounds__(256)
-transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t T, int64_t K) {
+transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t T, int64_t K,
+                     const int32_t* __restrict__ srcs) {
     __shared__ float tile[32][33];
     const int64_t t0 = (int64_t)blockIdx.x * 32, k0 = (int64_t)blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int64_t k = k0 + ty + 8 * j, t = t0 + tx;
-        tile[ty + 8 * j][tx] = (k < K && t < T) ? in[k * T + t] : 0.f;
+        float v = 0.f;
+        if (k < K && t < T) {
+            const int src = srcs ? srcs[k] : (int)k;
+            v = in[(int64_t)(src & ~KMAP_MIRROR) * T + ((src & KMAP_MIRROR) ? mirrored_frame(t, T) : t)];
+        }
+        tile[ty + 8 * j][tx] = v;
     }
     __syncthreads();
 #pragma unroll
@@ -106,11 +154,12 @@ transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int6
     }
 }
 
-int launch_transpose_f32(psa_ctx* c, const float* d_slab, float* d_out, int64_t T, int64_t K) {
+int launch_transpose_f32(psa_ctx* c, const float* d_slab, float* d_out, int64_t T, int64_t K, const int32_t* d_srcs) {
+    if (K == 0) return PSA_OK;
     const int64_t gy = (K + 31) / 32;
     PSA_REQUIRE(gy <= 65535, "too many k-points for one transpose launch");
     dim3 grid((unsigned)((T + 31) / 32), (unsigned)gy);
-    hipLaunchKernelGGL(transpose_f32_kernel, grid, dim3(256), 0, c->stream, d_slab, d_out, T, K);
+    hipLaunchKernelGGL(transpose_f32_kernel, grid, dim3(256), 0, c->stream, d_slab, d_out, T, K, d_srcs);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
 }

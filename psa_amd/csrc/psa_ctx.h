@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -150,6 +151,10 @@ struct PlaneSet {
     uint64_t             last_use = 0;
 };
 
+// Entry of a k map (psa_ctx::kmap): output column k takes slab row (entry & ~KMAP_MIRROR); with
+// KMAP_MIRROR set that row belongs to -k and is read as conj S[(T-w) mod T]  (k2_epilogue.hip)
+constexpr int KMAP_MIRROR = (int)0x80000000u;
+
 // page-locked staging buffers + copy stream of the host->device pipeline (psa_data_upload,
 // psa_sed_project_upload)
 struct Stager {
@@ -202,11 +207,27 @@ struct psa_ctx {
     psa::DevBuf d_slab;      // k-major: (K_total,3,T) c64  or (K_total,T) f32
     psa::DevBuf d_out;       // reference layout: (T,K_total,3) c64 or (T,K_total) f32
     psa::DevBuf d_aux;       // (T,K_total) f32 for intensity / chiral phase of the result
-    int64_t res_T = 0, res_K = 0;
+    int64_t res_T = 0, res_K = 0;           // frames; ROWS of the slab (= k-vectors projected)
     bool    res_intensity = false;
+    // k-vectors of the result when pairs (k, -k) / duplicates were folded: out_K columns, column k
+    // from slab row kmap[k] (KMAP_MIRROR: as the partner of that row); empty = the slab's rows as they are
+    int64_t              out_K = 0;
+    std::vector<int32_t> kmap;
+    psa::DevBuf          d_kmap, d_cols;
+    int64_t              opt_fold_pairs = 1;
+    psa::DevBuf          d_inten;                 // (T,out_K) f32: sum_c |d_out|^2 of a finalized complex result
+    bool                 inten_valid = false;
     bool    slab_valid = false, out_valid = false;
 
     std::map<std::pair<int64_t, int64_t>, psa::FftPlan> plans;   // (T, batch)
+    // rocFFT compiles the kernels of a length at run time on first use (tens to hundreds of ms): when a
+    // trajectory of T frames becomes resident a host thread builds a small plan of that length, so the
+    // first calculation finds the kernels compiled (and, through the per-user cache file, so does the
+    // next process)
+    std::thread  fft_primer;
+    psa::FftPlan primed;
+    int64_t      primed_T = 0;
+    int64_t      opt_fft_prime = 1;
 
     psa::TimingState timing;
     double oneoff_ms[4] = {0, 0, 0, 0};   // host wall clock of work done once: rocFFT plan builds, magnitude passes,
@@ -268,12 +289,15 @@ int    launch_k1_planes(psa_ctx* c, const void* d_planes, const void* d_phase, f
 
 // --- k2_epilogue.hip
 int launch_dft_bin(psa_ctx* c, const float2* d_q, int64_t T, int64_t bin, float2* d_out3);
-// rows of k-vectors [k_first, k_first + K) of a K_pitch-vector result -> their columns of (T, K_pitch, 3)
-int launch_scale_transpose_c64(psa_ctx* c, const float2* d_slab_rows, float2* d_out, int64_t T, int64_t K, int64_t K_pitch,
-                               int64_t k_first);
+// n output columns of a K_pitch-column result (T, K_pitch, 3) from rows of the k-major slab: column
+// d_cols[i] (null: col_first + i) from row d_srcs[i] (null: src_first + i; KMAP_MIRROR: the partner
+// -k of the row's k-vector); d_inten (may be null): sum_c |.|^2 of the same columns into (T, K_pitch)
+int launch_scale_transpose_c64(psa_ctx* c, const float2* d_slab, float2* d_out, float* d_inten, int64_t T, int64_t n,
+                               int64_t K_pitch, int64_t col_first, int64_t src_first, const int32_t* d_cols,
+                               const int32_t* d_srcs);
 int launch_intensity_accumulate(psa_ctx* c, const float2* d_q, float* d_slab_rows, int64_t T,
                                 int64_t K_local, bool first_group);
-int launch_transpose_f32(psa_ctx* c, const float* d_slab, float* d_out, int64_t T, int64_t K);
+int launch_transpose_f32(psa_ctx* c, const float* d_slab, float* d_out, int64_t T, int64_t K, const int32_t* d_srcs);
 int launch_result_intensity(psa_ctx* c, const float2* d_out, float* d_int, int64_t n_tk);
 int launch_result_chiral_c(psa_ctx* c, const float2* d_out, float* d_phase, int64_t n_tk, int c1, int c2);
 

@@ -164,7 +164,7 @@ def _recv_msg(sock, limit: int = 1 << 36) -> bytes:
 
 
 # Wire format of the host rendezvous: a JSON header describing a tree of None / bool / int / float /
-# str / bytes / ndarray / list, followed by the raw buffers of the bytes and ndarray leaves.  Nothing
+# str / bytes / ndarray / list / dict with string keys, followed by the raw buffers of the bytes and ndarray leaves.  Nothing
 # received from the network is ever executed or unpickled.
 def _encode(obj) -> bytes:
     blobs: List[bytes] = []
@@ -185,6 +185,8 @@ def _encode(obj) -> bytes:
             return {"a": [a.dtype.str, list(a.shape)]}
         if isinstance(o, (list, tuple)):
             return {"l": [walk(x) for x in o]}
+        if isinstance(o, dict) and all(isinstance(k, str) for k in o):
+            return {"d": [[k, walk(v)] for k, v in o.items()]}
         raise TypeError(f"{type(o).__name__} cannot cross the rendezvous")
 
     head = json.dumps(walk(obj)).encode()
@@ -215,6 +217,8 @@ def _decode(buf: bytes):
             shape = tuple(int(x) for x in t["a"][1])
             count = int(np.prod(shape, dtype=np.int64))
             return np.frombuffer(take(count * dt.itemsize), dtype=dt, count=count).reshape(shape).copy()
+        if "d" in t:
+            return {str(k): walk(v) for k, v in t["d"]}
         return [walk(x) for x in t["l"]]
 
     return walk(tree)
@@ -328,8 +332,15 @@ class KShardGroup:
         self.has_result = False
         self.transport = "rccl"
         self.last_mode = "k"                 # what the last run actually did
+        self.last_projected_k = 0            # k-vectors projected by the last run (after pair folding)
+        self.fold_pairs = True               # PSA_OPT_FOLD_PAIRS across ranks
         self._slice = None                   # (weakref to the whole array, frame range, the slice view)
+        self.transport_error = None          # why RCCL could not be used (transport == "host")
         if self.nranks > 1:
+            # the host driver of this pool supports dmabuf IPC only: without this RCCL's peer-memory
+            # exchange fails with "hipIpcGetMemHandle: invalid argument" (must be set before the
+            # communicator forms; a launcher's own setting wins)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             uid = engine.new_unique_id() if self.rank == 0 else None
             uid = exchange.broadcast(uid, 0)
             err = None
@@ -351,6 +362,7 @@ class KShardGroup:
                     engine.comm_destroy()
             if errors:
                 self.transport = "host"
+                self.transport_error = errors[0]
                 logger.warning("RCCL communicator could not be formed (%s); slab rows will be exchanged "
                                "through the host rendezvous instead -- correct, but not the xGMI path",
                                errors[0].splitlines()[-1])
@@ -403,7 +415,18 @@ class KShardGroup:
         this rank holds the whole k-major slab.  Asynchronous on the engine's stream unless a host
         transport stands in for RCCL.  n_frames: frames of the whole trajectory (mode "frames";
         default: the slot's frames x nothing -- required there)."""
+        k_vectors = np.asarray(k_vectors)
+        kmap = None
+        if self.nranks > 1 and self.fold_pairs and hasattr(self.engine, "set_kmap") and len(k_vectors) > 1:
+            # k-vectors whose negation (or twin) is in the list are not projected by anyone: the unique
+            # vectors are sharded, the rank(s) that finalize install the map (psa_sed_set_kmap)
+            kmap, unique = _hip.k_pairs(k_vectors)
+            if len(unique) < len(k_vectors):
+                k_vectors = k_vectors[unique]
+            else:
+                kmap = None
         n_k = len(k_vectors)
+        self.last_projected_k = n_k
         mode = self.mode_for(n_k, n_frames) if self.nranks > 1 else "k"
         self.last_mode = mode
         off, cnt = self.ranges(n_k, n_frames)
@@ -438,6 +461,8 @@ class KShardGroup:
             else:
                 self._host_gather(root, off, cnt, T, intensity)
         self.has_result = self.gather_mode == "all" or self.rank == self.root
+        if kmap is not None and self.has_result:
+            self.engine.set_kmap(kmap)
 
     def _host_gather(self, root, off, cnt, T, intensity):
         """Stand-in for psa_sed_gather when RCCL is unavailable: D2H of this rank's rows, exchange
@@ -458,14 +483,16 @@ class KShardGroup:
             if t_cnt[r] > 0 and n > 0:
                 self.engine.fs_write(int(t_off[r]), np.asarray(q)[lo:lo + n])
 
-    def run(self, slot, data, mean_pos_all, k_vectors, groups, flags, T: int, fetch: bool = True):
-        """Residency + projection + exchange + (on the ranks that receive it) the result."""
+    def run(self, slot, data, mean_pos_all, k_vectors, groups, flags, T: int, fetch: bool = True,
+            with_intensity: bool = False):
+        """Residency + projection + exchange + (on the ranks that receive it) the result; with_intensity:
+        (result, sum_c |result|^2) for a complex result."""
         self.ensure_resident(slot, data, len(k_vectors))
         self.project(slot, mean_pos_all, k_vectors, groups, flags, n_frames=T)
         if not self.has_result:
             self.engine.synchronize()
-            return None
-        return self.engine.finalize(T, len(k_vectors), bool(flags & _hip.F_INTENSITY), fetch)
+            return (None, None) if with_intensity else None
+        return self.engine.finalize(T, len(k_vectors), bool(flags & _hip.F_INTENSITY), fetch, with_intensity=with_intensity)
 
     def close(self):
         if self.nranks > 1:

@@ -148,6 +148,30 @@ CALC_WIDE_CASES = [
 ]
 
 
+# `calculate` cases whose k-lists hold pairs (k, -k) and repeated vectors: the library projects one
+# vector of each pair and writes the partner's columns from it (PSA_OPT_FOLD_PAIRS: S(-k)[w] =
+# conj S(k)[(T-w) mod T]); the REFERENCE computed every vector on its own.  Grids symmetric about
+# Gamma (examples/k_grid_heatmap_example.py:33-38) with an even and an odd point count (the odd one
+# holds Gamma itself), a partly symmetric grid, a non-power-of-two T, displacement mode, an
+# incoherent run, a list long enough for the block-by-block result path (400 k-vectors), and a
+# hand-made list: a path, its mirror image in reverse order and two repeated vectors.  A grid that
+# must NOT fold (k_fixed != 0) is `w_grid_xy_6x7` above.  Stored like the wide cases.
+_G66 = ("grid", "xy", (-1.5, 1.5), (-1.0, 1.0), 6, 6, 0.0)
+CALC_SYM_CASES = [
+    dict(name="s_grid_xy_6x6_coh", traj="a", k=_G66),
+    dict(name="s_grid_xy_6x6_inc", traj="a", k=_G66, kw=dict(basis_atom_types=[1, 2], summation_mode="incoherent")),
+    dict(name="s_grid_xy_5x5_gamma", traj="a", k=("grid", "xy", (-1.0, 1.0), (-2.0, 2.0), 5, 5, 0.0)),
+    dict(name="s_grid_xy_partial", traj="a", k=("grid", "xy", (-1.5, 1.0), (-1.0, 1.0), 6, 6, 0.0)),
+    dict(name="s_grid_yz_T100", traj="c", k=("grid", "yz", (-2.0, 2.0), (-1.0, 1.0), 4, 6, 0.0)),
+    dict(name="s_grid_zx_disp", traj="b", k=("grid", "zx", (-1.0, 1.0), (-3.0, 3.0), 4, 8, 0.0),
+         ctor=dict(use_displacements=True)),
+    dict(name="s_grid_xy_idx_inc", traj="a", k=_G66,
+         kw=dict(basis_atom_indices=[list(range(0, 40)), list(range(30, 64)) + [1, 1]], summation_mode="incoherent")),
+    dict(name="s_grid_xy_20x20", traj="a", k=("grid", "xy", (-3.5, 3.5), (-3.5, 3.5), 20, 20, 0.0)),
+    dict(name="s_mirrored_path", traj="a", k=("mirrored_path", [1, 1, 0], 2.0, 21, None)),
+]
+
+
 def c1_inputs():
     """BASELINE configuration 1 (512 atoms x 4096 steps x 32 k-points, [100], bz 4.0, dt 0.02:
     examples/Si_config.yaml's shape) as arrays: the synthetic velocities of psa_amd/synth.py
@@ -196,6 +220,12 @@ def k_from_spec(calc, spec):
     if spec[0] == "path":
         _, d, cov, n_k, lat = spec
         mags, vecs = calc.get_k_path(d, cov, n_k, lat_param=lat)
+        return mags, vecs, None
+    if spec[0] == "mirrored_path":           # the path, its negation in reverse order, two vectors once more
+        _, d, cov, n_k, lat = spec
+        mags, vecs = calc.get_k_path(d, cov, n_k, lat_param=lat)
+        vecs = np.concatenate([-vecs[::-1], vecs[1:], vecs[3:5]]).astype(np.float32)
+        mags = np.concatenate([-mags[::-1], mags[1:], mags[3:5]]).astype(np.float32)
         return mags, vecs, None
     _, plane, rx, ry, nkx, nky, fixed = spec
     return calc.get_k_grid(plane, rx, ry, nkx, nky, fixed)

@@ -68,6 +68,26 @@ def main():
         cx, cy, cz = d["cells"]
         return SEDCalculator(tr, cx, cy, cz, **ctor)
 
+    # ---- calculate() on k-lists with (k, -k) pairs and repeated vectors -------------------------
+    out = {}
+    for case in C.CALC_SYM_CASES:
+        calc = make_calc(case["traj"], **case.get("ctor", {}))
+        mags, vecs, shape = C.k_from_spec(calc, case["k"])
+        kw = C.realise_kw(case.get("kw", {}))
+        if shape is not None:
+            kw["k_grid_shape"] = shape
+        sed = calc.calculate(mags, vecs, **kw)
+        n = case["name"]
+        out[f"{n}/k_mags"], out[f"{n}/k_vecs"] = mags, vecs
+        out[f"{n}/sed_rows"] = sed.sed[::C.WIDE_SED_STRIDE]
+        out[f"{n}/sed_shape"] = np.array(sed.sed.shape)
+        out[f"{n}/is_complex"] = np.array(sed.is_complex)
+        out[f"{n}/intensity"] = sed.intensity if sed.is_complex else sed.sed
+    np.savez_compressed(HERE / "calc_sym.npz", **out)
+    if "--only-sym" in sys.argv:                         # (added in round 3; the other fixtures are unchanged)
+        print(f"calc_sym.npz {(HERE / 'calc_sym.npz').stat().st_size / 1024:8.1f} KiB")
+        return
+
     # ---- calculate() cases ------------------------------------------------
     out = {}
     for case in C.CALC_CASES:

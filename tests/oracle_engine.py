@@ -70,6 +70,7 @@ class OracleEngine:
             self._slab = np.zeros((K_total, T) if intensity else (K_total, 3, T),
                                   np.float32 if intensity else np.complex64)
             self._meta = (T, K_total, intensity)
+        self._kmap = None
         rows = slice(k_offset, k_offset + K)
         acc = np.zeros((T, K), np.float32)
         for g in groups:
@@ -87,10 +88,13 @@ class OracleEngine:
         if intensity:
             self._slab[rows] = acc.T
 
-    def calculate(self, slot, mean_pos_all, k_vectors, groups=None, flags=0):
+    def calculate(self, slot, mean_pos_all, k_vectors, groups=None, flags=0, with_intensity=False):
         self.project(slot, mean_pos_all, k_vectors, groups, flags)
         T = self.slots[slot].shape[0]
-        return self.finalize(T, len(k_vectors), bool(flags & _hip.F_INTENSITY))
+        return self.finalize(T, len(k_vectors), bool(flags & _hip.F_INTENSITY), with_intensity=with_intensity)
+
+    def set_kmap(self, kmap):
+        self._kmap = np.asarray(kmap, np.uint32)
 
     def gather(self, root, k_offsets, k_counts):
         for r, eng in self._peers.items():
@@ -106,9 +110,21 @@ class OracleEngine:
     def slab_write(self, row0, rows):
         self._slab[row0:row0 + rows.shape[0]] = rows
 
-    def finalize(self, T, K, intensity, fetch=True):
-        self._out = self._slab.T.copy() if intensity else self._slab.transpose(2, 0, 1).copy()
-        return self._out if fetch else None
+    def finalize(self, T, K, intensity, fetch=True, with_intensity=False):
+        slab, kmap = self._slab, getattr(self, "_kmap", None)
+        if kmap is not None:                     # folded pairs: column k from row kmap[k], mirrored partners
+            self._kmap = None                    # (the map belongs to the result that was just projected)
+            back = (-np.arange(T)) % T           # S(-k)[w] = conj S(k)[(T-w) mod T]
+            rows = slab[kmap & 0x7FFFFFFF]
+            flip = (kmap >> 31).astype(bool)
+            rows[flip] = rows[flip][..., back] if intensity else np.conj(rows[flip][..., back])
+            slab = rows
+        assert slab.shape[0] == K, (slab.shape, K)
+        self._out = slab.T.copy() if intensity else slab.transpose(2, 0, 1).copy()
+        if not with_intensity:
+            return self._out if fetch else None
+        inten = None if intensity else np.sum(np.abs(self._out) ** 2, axis=-1).astype(np.float32)
+        return (self._out, inten) if fetch else (None, None)
 
     def result_chiral_phase(self, T, K, c1, c2):
         return O.chiral_phase(self._out[:, :, c1], self._out[:, :, c2], "C")

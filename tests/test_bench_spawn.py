@@ -37,6 +37,23 @@ def test_bench_spawns_its_ranks_and_prints_one_line(shard, n):
     assert sum(cfg["k_points_per_rank"]) == 32 and len(cfg["k_points_per_rank"]) == n
     assert cfg["shard_mode"] == ("k" if shard == "k" else "frames")           # 32 k over n ranks: auto -> frames
     assert out["scaling"] == "strong" and out["higher_is_better"] is True
+    # what makes the N > 1 line explain itself (round 3): every rank's own stage times beside the
+    # per-stage maximum, why RCCL was not used, the drop-in call on the root, the intensity-only
+    # gather, and the north star's k-partitioning measured beside frame sharding when auto picked that
+    stage_names = {"h2d", "phase", "project", "fft", "epilogue", "gather", "transpose", "d2h"}
+    assert set(out["stages_ms_per_step"]) == stage_names
+    assert len(out["stages_ms_per_step_by_rank"]) == n
+    assert all(set(r) == stage_names | {"k1_avg_launch_ms"} for r in out["stages_ms_per_step_by_rank"])
+    assert cfg["transport_error"] == "stub engine: no RCCL" and "NOT xGMI" in cfg["transport_note"]
+    e2e = out["end_to_end"]
+    assert e2e["ms"] >= e2e["calculate_only_ms"] > 0 and e2e["result_bytes"] == 28 * 4096 * 32
+    inten = out["variants"]["intensity_only"]
+    assert inten["shard_mode"] == cfg["shard_mode"] and inten["ms_per_step"] > 0
+    if shard == "k":
+        assert "shard_k" not in out["variants"]
+    else:
+        sk = out["variants"]["shard_k"]
+        assert sk["shard_mode"] == "k" and sum(sk["k_points_per_rank"]) == 32 and len(sk["k_points_per_rank"]) == n
 
 
 def test_bench_runs_as_one_rank_under_a_launcher():
@@ -45,6 +62,7 @@ def test_bench_runs_as_one_rank_under_a_launcher():
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads(res.stdout.strip())
     assert out["n_gpus"] == 1 and out["config"]["parallelism"] == "single GPU"
+    assert "stages_ms_per_step_by_rank" not in out and "transport_error" not in out["config"]
 
 
 def test_a_failing_rank_fails_the_launch():

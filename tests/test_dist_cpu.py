@@ -105,9 +105,11 @@ def _sharded_worker(rank, world, port, backend, gather, results, no_rccl=False, 
         d = {k: z[k] for k in z.files}
     d["dt_ps"], d["cells"] = float(d["dt_ps"]), tuple(int(v) for v in d["cells"])
     eng = ExchangeEngine(rank=rank)
-    group = D.KShardGroup(eng, ex, gather=gather, root=0, balance=balance, mode=mode)
+    group = D.KShardGroup(eng, ex, gather=gather, root=0, balance=balance, mode=mode.split("+")[0])
     calc = conftest.make_calculator(d).attach(shard_group=group)
     mags, vecs = calc.get_k_path([1, 1, 0], 2.0, 7)               # 7 k-points over 2 ranks: 4 + 3
+    if mode.endswith("+grid"):                                    # 4 x 6 grid symmetric about Gamma: 12 pairs
+        mags, vecs, _ = calc.get_k_grid("xy", (-2.0, 2.0), (-1.0, 1.0), 4, 6, 0.0)
     out = {}
     for name, kw in (("coh", {}), ("inc", dict(basis_atom_types=[1, 2], summation_mode="incoherent"))):
         sed = calc.calculate(mags, vecs, **kw)
@@ -168,6 +170,50 @@ def test_two_rank_sharded_calculate_equals_unsharded(backend, gather, no_rccl, b
             continue
         assert conftest.rel_max(res[rank]["coh"], ref_c) <= 2e-6
         assert conftest.rel_max(res[rank]["inc"], ref_i) <= 2e-6
+
+
+@pytest.mark.parametrize("mode, gather", [("k+grid", "all"), ("frames+grid", "root")])
+def test_two_rank_sharded_grid_projects_each_pair_once(mode, gather):
+    """A k-grid symmetric about Gamma over two ranks: the 12 unique k-vectors are sharded 6 + 6, the
+    ranks that finalize install the k map, and the 24-point result equals the unsharded oracle."""
+    import conftest
+    from oracle import psa_oracle as O
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        results = mgr.dict()
+        procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, "tcp", gather, results, False, None, mode))
+                 for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+        res = {r: dict(results[r]) for r in range(world)}
+    with np.load(conftest.GOLDEN / "traj_a.npz") as z:
+        d = {k: z[k] for k in z.files}
+    calc = conftest.make_calculator(dict(d, dt_ps=float(d["dt_ps"]), cells=tuple(int(v) for v in d["cells"])))
+    _, vecs, _ = calc.get_k_grid("xy", (-2.0, 2.0), (-1.0, 1.0), 4, 6, 0.0)
+    ref_c, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], float(d["dt_ps"]), vecs)
+    ref_i, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], float(d["dt_ps"]), vecs,
+                              basis_atom_types=[1, 2], summation_mode="incoherent")
+    assert res[0]["coh_range"] == (0, 6, 12) and res[1]["inc_range"] == (6, 6, 12)      # 12 of 24 projected
+    for rank in range(world):
+        if gather == "root" and rank != 0:
+            assert res[rank]["coh"] is None
+            continue
+        assert res[rank]["coh"].shape == ref_c.shape and res[rank]["inc"].shape == ref_i.shape
+        assert conftest.rel_max(res[rank]["coh"], ref_c) <= 2e-6
+        assert conftest.rel_max(res[rank]["inc"], ref_i) <= 2e-6
+
+
+def test_rendezvous_wire_format_round_trips_dicts():
+    obj = {"a": 1.5, "b": [1, None, "x", {"c": np.arange(3, dtype=np.int32)}], "raw": b"\x00\x01"}
+    back = dist._decode(dist._encode(obj))
+    assert back["a"] == 1.5 and back["b"][:3] == [1, None, "x"] and back["raw"] == b"\x00\x01"
+    assert np.array_equal(back["b"][3]["c"], np.arange(3))
+    with pytest.raises(TypeError):
+        dist._encode({1: 2})
 
 
 def test_exchange_defaults_single_process():

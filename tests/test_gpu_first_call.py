@@ -1,0 +1,58 @@
+"""First-call latency across processes: rocFFT compiles the kernels of a transform length at run
+time; libpsa_hip points rocFFT's kernel cache at a per-user file (psa_create) and builds a small plan
+of the trajectory's length on a host thread while the trajectory uploads (PSA_OPT_FFT_PRIME).  Each
+child below is a fresh Python process on the same GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r'''
+import json, sys, time
+sys.path.insert(0, %r)
+import numpy as np
+from psa_amd import _hip
+prime = int(sys.argv[1])
+eng = _hip.Engine(0)
+eng.set_option(_hip.OPT_FFT_PRIME, prime)
+T, N, K = 65536, 64, 48
+vel = np.random.default_rng(0).standard_normal((T, N, 3)).astype(np.float32)
+eng.ensure_resident(0, vel)
+eng.oneoff_stats()
+kv = np.linspace(0.1, 1, K, dtype=np.float32)[:, None] * np.ones(3, np.float32)
+mean = np.zeros((N, 3), np.float32)
+t0 = time.perf_counter()
+eng.project(0, mean, kv)
+out = eng.finalize(T, K, False)
+first_ms = 1e3 * (time.perf_counter() - t0)
+plan_ms = eng.oneoff_stats()["rocfft_plan"]
+print(json.dumps(dict(plan_ms=plan_ms, first_ms=first_ms, checksum=float(np.abs(out).sum()))))
+''' % str(ROOT)
+
+
+def _child(cache_dir, prime):
+    env = dict(os.environ, PSA_CACHE_DIR=str(cache_dir))
+    env.pop("ROCFFT_RTC_CACHE_PATH", None)
+    res = subprocess.run([sys.executable, "-c", CHILD, str(prime)], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    return json.loads(res.stdout.strip().splitlines()[-1])
+
+
+def test_second_process_finds_the_fft_kernels_compiled(tmp_path):
+    cache = tmp_path / "psa_cache"
+    first = _child(cache, 0)                       # compiles, fills the cache file
+    db = cache / "rocfft_rtc_cache.db"
+    assert db.exists() and db.stat().st_size > 0
+    second = _child(cache, 0)                      # loads the compiled kernels instead
+    third = _child(cache, 1)                       # ... and builds the plan beside the upload
+    print(f"rocFFT plan build, T = 65536: first process {first['plan_ms']:.1f} ms, second {second['plan_ms']:.1f} ms, "
+          f"second with the plan primed during the upload {third['plan_ms']:.1f} ms")
+    assert first["checksum"] == second["checksum"] == third["checksum"] > 0
+    assert second["plan_ms"] <= 0.8 * first["plan_ms"]
+    assert third["plan_ms"] <= 20.0

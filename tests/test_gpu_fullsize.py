@@ -147,6 +147,49 @@ def test_config3_planted_modes_and_shard_invariance(engine, config3):
     np.testing.assert_allclose(engine.result_intensity(T, K), inten, rtol=1e-6, atol=0)
 
 
+def test_config3_public_calculate_at_full_size(engine, config3):
+    """The PUBLIC call at configuration 3 -- SEDCalculator.calculate(k_mags, k_vecs, basis_atom_types=[1, 2])
+    on the 25.8 GB trajectory generated in HBM: 256 k-vectors leave block by block (psa_sed_calculate's
+    pipelined path), the intensity comes with them.  Held to (a) the engine-level project + finalize
+    path over the whole (T, K, 3) array, (b) the oracle: the inverse FFT of 16 result columns gives
+    q(t), compared on 64 blocks of 32 frames spread over the trajectory with the oracle's projection
+    of the very same frames (rebuilt on the host by the generator's NumPy twin), (c) its own
+    companion intensity."""
+    import weakref
+    from psa_amd import SEDCalculator, Trajectory, _hip, synth
+    spec, r0, types, tables, vecs = (config3[k] for k in ("spec", "r0", "types", "tables", "vecs"))
+    T, N, K = spec.n_frames, spec.n_atoms, len(vecs)
+    box = synth.lattice(spec.cells)[2]
+    stand_in = np.broadcast_to(np.float32(0), (T, N, 3))          # the trajectory exists only in HBM
+    pos = np.broadcast_to(r0, (T, N, 3))
+    calc = SEDCalculator(Trajectory(pos, stand_in, types, np.broadcast_to(np.float32(0), (T,)), box, np.diag(box).copy(),
+                                    np.zeros(3, np.float32), spec.dt_ps), *spec.cells).attach(engine=engine)
+    engine.adopt(_hip.SLOT_VELOCITIES, stand_in)
+    calc._mean_cache = (weakref.ref(pos), r0, _hip.Engine._fingerprint(pos))
+    sed = calc.calculate(np.zeros(K, np.float32), vecs, basis_atom_types=[1, 2])
+    assert sed.sed.shape == (T, K, 3) and sed.sed.dtype == np.complex64 and sed.is_complex
+    inten = sed.intensity
+    assert inten.shape == (T, K) and inten.dtype == np.float32
+    rows = np.arange(0, T, 257)
+    np.testing.assert_allclose(inten[rows], np.sum(np.abs(sed.sed[rows]) ** 2, axis=-1), rtol=5e-6)
+    # (a) the engine-level path, whole array
+    engine.project(_hip.SLOT_VELOCITIES, r0, vecs, None, 0)
+    plain = engine.finalize(T, K, False)
+    assert rel_max(sed.sed, plain) <= 2e-6
+    del plain
+    # (b) the oracle on sampled frames, through the inverse transform of 16 columns
+    pick = np.linspace(0, K - 1, 16).round().astype(int)
+    q = np.fft.ifft(sed.sed[:, pick, :].astype(np.complex128), axis=0) * T          # (T, 16, 3)
+    phase = O.phase_table(vecs[pick], r0)
+    scale = float(np.max(np.abs(q)))
+    worst = 0.0
+    for t0 in np.linspace(0, T - 32, 64).astype(int) // 32 * 32:
+        block = synth.velocities_block(spec, tables, int(t0), 32)
+        ref = O.project_group(block, phase)                                         # (32, 16, 3)
+        worst = max(worst, float(np.max(np.abs(q[t0:t0 + 32] - ref))) / scale)
+    assert worst <= TOL, worst
+
+
 # ---------------------------------------------------------------------------- full-size helpers
 def _device_config(engine, name):
     """The configuration's trajectory generated in HBM + the host objects that describe it."""

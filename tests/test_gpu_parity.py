@@ -137,6 +137,49 @@ def test_calculate_wide_matches_reference_golden(case, golden, trajs, engine):
     assert rel_max(again.intensity if again.is_complex else again.sed, golden[f"{name}/intensity"]) <= TOL
 
 
+@pytest.mark.parametrize("case", C.CALC_SYM_CASES, ids=[c["name"] for c in C.CALC_SYM_CASES])
+def test_calculate_sym_matches_reference_golden(case, golden, trajs, engine):
+    """k-lists with (k, -k) pairs and repeated vectors (grids symmetric about Gamma, with and without
+    Gamma itself, partly symmetric, T = 100, displacement mode, incoherent, 400 vectors through the
+    block-by-block result path, a hand-mirrored path): the library projects one vector of each pair
+    (PSA_OPT_FOLD_PAIRS) and must land on the REFERENCE's output, which computed every vector."""
+    from psa_amd import _hip
+    d = trajs[case["traj"]]
+    name = case["name"]
+    calc = _calc(d, engine, **case.get("ctor", {}))
+    mags, vecs, shape = C.k_from_spec(calc, case["k"])
+    np.testing.assert_allclose(vecs, golden[f"{name}/k_vecs"], rtol=3e-7, atol=1e-9)
+    mags, vecs = golden[f"{name}/k_mags"], golden[f"{name}/k_vecs"]
+    kmap, unique = _hip.k_pairs(vecs)
+    assert len(unique) < len(vecs)                                  # these lists do fold
+    kw = C.realise_kw(case.get("kw", {}))
+    if shape is not None:
+        kw["k_grid_shape"] = shape
+    for attempt in range(3):             # streamed first call; resident (pipelined for 400 vectors); cached planes
+        sed = calc.calculate(mags, vecs, **kw)
+        assert sed.sed.shape == tuple(golden[f"{name}/sed_shape"])
+        assert sed.is_complex == bool(golden[f"{name}/is_complex"])
+        assert rel_max(sed.sed[::C.WIDE_SED_STRIDE], golden[f"{name}/sed_rows"]) <= TOL
+        assert rel_max(sed.intensity if sed.is_complex else sed.sed, golden[f"{name}/intensity"]) <= TOL
+    # ... and the same with folding switched off projects every vector: same result to rounding
+    engine.set_option(_hip.OPT_FOLD_PAIRS, 0)
+    try:
+        plain = calc.calculate(mags, vecs, **kw)
+    finally:
+        engine.set_option(_hip.OPT_FOLD_PAIRS, 1)
+    assert rel_max(plain.sed, sed.sed) <= 2e-6
+
+
+def test_lists_without_pairs_are_projected_whole(golden, engine):
+    """k_fixed != 0: no vector's negation is in the grid -- nothing folds (the shortcut must not be
+    taken); same for a k-path from Gamma outwards."""
+    from psa_amd import _hip
+    for name in ("w_grid_xy_6x7", "w_coh_all_k140"):
+        vecs = golden[f"{name}/k_vecs"]
+        kmap, unique = _hip.k_pairs(vecs)
+        assert len(unique) == len(vecs) and np.array_equal(kmap, np.arange(len(vecs)))
+
+
 def test_config1_matches_reference(engine):
     """BASELINE configuration 1 at full size -- 512 atoms x 4096 steps x 32 k-points, [100] path,
     bz 4.0 -- through the public API against the REAL reference's output (c1_reference.npz)."""

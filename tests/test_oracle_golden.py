@@ -16,6 +16,11 @@ def _k_for(case, d):
         _, direction, cov, n_k, lat = spec
         mags, vecs = O.k_path(d["box_matrix"], cx, cy, cz, direction, cov, n_k, lat)
         return mags, vecs
+    if spec[0] == "mirrored_path":
+        _, direction, cov, n_k, lat = spec
+        mags, vecs = O.k_path(d["box_matrix"], cx, cy, cz, direction, cov, n_k, lat)
+        return (np.concatenate([-mags[::-1], mags[1:], mags[3:5]]).astype(np.float32),
+                np.concatenate([-vecs[::-1], vecs[1:], vecs[3:5]]).astype(np.float32))
     _, plane, rx, ry, nkx, nky, fixed = spec
     mags, vecs, _ = O.k_grid(plane, rx, ry, nkx, nky, fixed)
     return mags, vecs
@@ -59,6 +64,52 @@ def test_calculate_wide_matches_reference(case, golden, trajs):
     assert bool(golden[f"{name}/is_complex"]) == is_complex
     assert rel_max(sed[::C.WIDE_SED_STRIDE], golden[f"{name}/sed_rows"]) <= 2e-6
     assert rel_max(O.intensity(sed) if is_complex else sed, golden[f"{name}/intensity"]) <= 2e-6
+
+
+@pytest.mark.parametrize("case", C.CALC_SYM_CASES, ids=[c["name"] for c in C.CALC_SYM_CASES])
+def test_calculate_sym_matches_reference(case, golden, trajs):
+    """k-lists with (k, -k) pairs and repeated vectors: the oracle (which, like the reference,
+    computes every vector on its own) against the reference's output."""
+    d = trajs[case["traj"]]
+    name = case["name"]
+    mags, vecs = _k_for(case, d)
+    np.testing.assert_allclose(vecs, golden[f"{name}/k_vecs"], rtol=3e-7, atol=1e-9)
+    vecs = golden[f"{name}/k_vecs"]
+    kw = C.realise_kw(case.get("kw", {}))
+    sed, _, is_complex = O.calculate(
+        d["positions"], d["velocities"], d["types"], d["dt_ps"], vecs,
+        use_displacements=case.get("ctor", {}).get("use_displacements", False), **kw)
+    assert tuple(golden[f"{name}/sed_shape"]) == sed.shape
+    assert bool(golden[f"{name}/is_complex"]) == is_complex
+    assert rel_max(sed[::C.WIDE_SED_STRIDE], golden[f"{name}/sed_rows"]) <= 2e-6
+    assert rel_max(O.intensity(sed) if is_complex else sed, golden[f"{name}/intensity"]) <= 2e-6
+
+
+@pytest.mark.parametrize("case", C.CALC_SYM_CASES, ids=[c["name"] for c in C.CALC_SYM_CASES])
+def test_reference_output_has_the_minus_k_symmetry(case, golden):
+    """The premise of PSA_OPT_FOLD_PAIRS, checked on the REFERENCE's own numbers: wherever -k is in the
+    list too, S(-k)[w] == conj S(k)[(T-w) mod T] and I(-k)[w] == I(k)[(T-w) mod T] -- to rounding
+    (float32 FFT of conj(q) vs conj of the FFT: <= 1e-6 of the peak), far inside the 1e-5 bar."""
+    name = case["name"]
+    vecs, inten = golden[f"{name}/k_vecs"], golden[f"{name}/intensity"]
+    rows = golden[f"{name}/sed_rows"]
+    T = int(golden[f"{name}/sed_shape"][0])
+    complex_out = bool(golden[f"{name}/is_complex"])
+    assert inten.shape == (T, len(vecs))
+    back = (-np.arange(T)) % T
+    stored = np.arange(T)[::C.WIDE_SED_STRIDE]                     # frequencies whose complex row is kept
+    pairs = 0
+    for i, k in enumerate(vecs):
+        for j in range(i):
+            if np.array_equal(-k, vecs[j]):
+                pairs += 1
+                assert rel_max(inten[:, i], inten[back, j]) <= 1e-6
+                if complex_out:
+                    both = [(a, b) for a, w in enumerate(stored) for b, v in enumerate(stored) if v == back[w]]
+                    a, b = np.array(both).T
+                    assert rel_max(rows[a, i], np.conj(rows[b, j])) <= 1e-6
+                break
+    assert pairs >= 6
 
 
 def test_config1_matches_reference():
