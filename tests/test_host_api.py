@@ -404,8 +404,11 @@ def test_rendezvous_wire_format_round_trips_and_rejects_garbage():
     assert back[:5] == [None, True, 3, 2.5, "text"] and back[5] == b"\x00\x01raw"
     np.testing.assert_array_equal(back[6], obj[6])
     assert back[6].dtype == np.complex64 and back[7] == [1.5, 7, [1, 2]] and back[8].shape == (0, 3)
+    assert dist._decode(dist._encode({"a": 1, "b": [2.0]})) == {"a": 1, "b": [2.0]}     # dicts with string keys do
     with pytest.raises(TypeError):
-        dist._encode({"a": 1})                                      # only plain data crosses
+        dist._encode({1: "a"})                                      # only plain data crosses
+    with pytest.raises(TypeError):
+        dist._encode({"f": len})
     with pytest.raises(TypeError):
         dist._encode(np.array([object()]))
     import pickle
