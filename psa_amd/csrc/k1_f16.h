@@ -94,23 +94,32 @@ __device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_byte_addr)
 // N consecutive 1-KiB pieces in ONE addressing setup: uniform 64-bit base in SGPRs + a 32-bit
 // per-lane offset; piece i adds the instruction offset 1024 i, which the hardware applies to the
 // global address AND to the LDS address (tools/probes/dma_offset.hip).  One M0 write, no VALU.
-template <int N>
+// NT: non-temporal cache policy (aux nt) -- for bytes this launch reads exactly once, streamed from HBM
+// (MI355X_MICROARCH.md "nt-weights": issued -> landed -18 %); never for data other workgroups re-read
+template <int N, bool NT = false>
 __device__ __forceinline__ void lds_dma16_group(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
     static_assert(N >= 1 && N <= 4, "instruction offsets reach 4095");
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
-    if constexpr (N == 1)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(dst) : "memory");
-    else if constexpr (N == 2)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
-                     "global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sbase), "s"(dst) : "memory");
-    else if constexpr (N == 3)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
-                     "global_load_lds_dwordx4 %0, %1 offset:1024\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048"
-                     ::"v"(voff), "s"(sbase), "s"(dst) : "memory");
-    else
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
-                     "global_load_lds_dwordx4 %0, %1 offset:1024\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048\n\t"
-                     "global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(sbase), "s"(dst) : "memory");
+#define PSA_DMA_ASM(P)                                                                                                         \
+    if constexpr (N == 1)                                                                                                      \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" P ::"v"(voff), "s"(sbase), "s"(dst) : "memory"); \
+    else if constexpr (N == 2)                                                                                                 \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" P "\n\t"                                \
+                     "global_load_lds_dwordx4 %0, %1 offset:1024" P ::"v"(voff), "s"(sbase), "s"(dst) : "memory");             \
+    else if constexpr (N == 3)                                                                                                 \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" P "\n\t"                                \
+                     "global_load_lds_dwordx4 %0, %1 offset:1024" P "\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048" P         \
+                     ::"v"(voff), "s"(sbase), "s"(dst) : "memory");                                                            \
+    else                                                                                                                       \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" P "\n\t"                                \
+                     "global_load_lds_dwordx4 %0, %1 offset:1024" P "\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048" P "\n\t"  \
+                     "global_load_lds_dwordx4 %0, %1 offset:3072" P ::"v"(voff), "s"(sbase), "s"(dst) : "memory");
+    if constexpr (NT) {
+        PSA_DMA_ASM(" nt")
+    } else {
+        PSA_DMA_ASM("")
+    }
+#undef PSA_DMA_ASM
 }
 // 12 bytes per lane, landing at dst + lane * 16
 __device__ __forceinline__ void lds_dma12(const void* g, unsigned lds_byte_addr) {
@@ -149,6 +158,9 @@ __host__ __device__ inline size_t plane_index(int64_t fg, int stage, int comp, i
     return ((size_t)(fg * n_stage + stage) * (3 * F16x2::NP) + (size_t)(comp * F16x2::NP + piece)) * PL_BLOCK_ELEMS +
            (size_t)r * K1_BA + (size_t)((((al >> 3) ^ pl_swizzle(r)) << 3) + (al & 7));
 }
-inline size_t plane_bytes(int64_t n_fg, int n_stage) { return (size_t)n_fg * n_stage * PL_STAGE_ELEMS * sizeof(_Float16); }
+// (+ 4 stages of padding: the planes kernel prefetches up to RING <= 4 stages past a frame group's end)
+inline size_t plane_bytes(int64_t n_fg, int n_stage) {
+    return ((size_t)n_fg * n_stage + 4) * PL_STAGE_ELEMS * sizeof(_Float16);
+}
 
 }  // namespace psa

@@ -343,7 +343,8 @@ phase_table_f16_kernel(const float* __restrict__ kvec, const float* __restrict__
     }
 }
 
-size_t pf16_table_bytes(int M_pad, int A_pad) { return (size_t)M_pad * A_pad * 2 * F16x2::NP; }
+// (+ 4 stages of a 128-row block as padding: the kernels prefetch up to RING <= 4 stages past an M block's end)
+size_t pf16_table_bytes(int M_pad, int A_pad) { return (size_t)M_pad * A_pad * 2 * F16x2::NP + 4 * F16x2::NP * 128 * K1_BA * 2; }
 
 int launch_phase_table_f16(psa_ctx* c, const float* d_kvec, const float* d_mean_all, const int* d_idx, void* d_phase,
                            const ProjGeom& g) {

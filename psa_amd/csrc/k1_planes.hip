@@ -33,11 +33,17 @@
 // 14 LDS reads of the next stage at the top of the stage 16.4 ms (an in-order wavefront cannot issue
 // its MFMAs behind a read burst that fills the LDS queue); the same with the reads paced one per two
 // MFMAs (sched_group_barrier) 14.9 ms -- no schedule moves the launch any more: it is power-limited.
+// 256: no non-temporal policy on the planes of a one-M-block launch    512: running source pointers
+// Timing-only experiments (WRONG results): 128 every V read an L2 hit; 1024 no MFMAs; 2048 the P' tile
+// always stage 0 (L2-hot)
 #ifndef PSA_K1P_X
-#define PSA_K1P_X 51        // product build: 1 + 2 + 16 + 32 (64 measured 3 % slower)
+#define PSA_K1P_X 563       // product build: 1 + 2 + 16 + 32 + 512 (64 measured 3 % slower)
 #endif
 #ifndef PSA_K1P_POS
 #define PSA_K1P_POS -1      // row tile after which waves 4-7 issue their DMA (-1: the middle one)
+#endif
+#ifndef PSA_K1P_RING1
+#define PSA_K1P_RING1 3     // ring slots of the 128-row variant when the launch has one M block (4 = all 160 KiB of LDS)
 #endif
 #ifndef PSA_K1P_PRIO
 #define PSA_K1P_PRIO 1      // which row half runs at s_setprio 1 (bit 2 of PSA_K1P_X)
@@ -64,7 +70,9 @@ struct K1pCfg {
     static_assert(RING >= 3, "stage s+1 read while s+2 .. s+RING travel");
 };
 
-template <int MT16_, int RING_>
+// NT_V: the launch has ONE M block, so every byte of the planes is read exactly once -> streamed with
+// the non-temporal policy (PSA_K1P_X bit 256 switches it off for comparison)
+template <int MT16_, int RING_, bool NT_V>
 __global__ void __launch_bounds__(512, 1)
 k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict__ Pb, float2* __restrict__ Q,
                  int64_t T, int64_t q_stride, int n_fg, int n_stage, int K, int n_mblk, int n_tblk, float qscale) {
@@ -115,13 +123,30 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
             lds_dma16(vp + (size_t)sc * C::V_GROUP_BYTES + 1024 * j, vdst + 1024 * j);
         }
     };
+    // bit 512: the sources of the next stage to fetch as running uniform pointers (one s_add_u32 /
+    // s_addc_u32 pair each per stage instead of clamp + 64-bit multiply-add); stages past the end are
+    // fetched from the bytes that follow (the next frame group / M block, or the RING stages of padding
+    // behind the buffers: k1_planes_tail_pad) and never read
+    const unsigned char* p_next = pbase;
+    const unsigned char* v_next = vbase;
     auto dma_stage = [&](int st, int slot) {
-        if constexpr ((PSA_K1P_X & 32) != 0) {
+        if constexpr ((PSA_K1P_X & 512) != 0) {
+            const unsigned dst = lds0 + slot * C::STAGE_BYTES;
+            if constexpr ((PSA_K1P_X & 4096) != 0)          // experiment: the HBM-served pieces first
+                lds_dma16_group<C::V_DMA, NT_V && (PSA_K1P_X & 256) == 0>(
+                    v_next, v_voff, dst + C::P_STAGE_BYTES + wf * C::V_GROUP_BYTES + 1024 * (wh * C::V_DMA));
+            lds_dma16_group<C::P_DMA>(p_next, p_voff, dst + 1024 * pw);
+            if constexpr ((PSA_K1P_X & 4096) == 0)
+                lds_dma16_group<C::V_DMA, NT_V && (PSA_K1P_X & 256) == 0>(
+                    v_next, v_voff, dst + C::P_STAGE_BYTES + wf * C::V_GROUP_BYTES + 1024 * (wh * C::V_DMA));
+            if constexpr ((PSA_K1P_X & 2048) == 0) p_next += C::P_STAGE_BYTES;
+            v_next += C::V_GROUP_BYTES;
+        } else if constexpr ((PSA_K1P_X & 32) != 0) {
             const int      sc = st < last ? st : last;
             const unsigned dst = lds0 + slot * C::STAGE_BYTES;
             lds_dma16_group<C::P_DMA>(pbase + (size_t)sc * C::P_STAGE_BYTES, p_voff, dst + 1024 * pw);
-            lds_dma16_group<C::V_DMA>(vbase + (size_t)sc * C::V_GROUP_BYTES, v_voff,
-                                      dst + C::P_STAGE_BYTES + wf * C::V_GROUP_BYTES + 1024 * (wh * C::V_DMA));
+            lds_dma16_group<C::V_DMA, NT_V && (PSA_K1P_X & 256) == 0>(
+                vbase + (size_t)sc * C::V_GROUP_BYTES, v_voff, dst + C::P_STAGE_BYTES + wf * C::V_GROUP_BYTES + 1024 * (wh * C::V_DMA));
         } else {
 #pragma unroll
             for (int i = 0; i < C::BATCH; ++i) dma_piece(i, st, slot);
@@ -169,6 +194,14 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((C::RING - 2) * C::BATCH) : "memory");   // stage 1 landed, slot 0 read
 
     auto mfma_tile = [&](int mt, int par, bool restart) {
+        if constexpr ((PSA_K1P_X & 1024) != 0) {        // timing experiment: operands consumed, no matrix work
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                asm volatile("" ::"v"(a[0][mt]), "v"(a[1][mt]), "v"(bs[par][c][0]), "v"(bs[par][c][1]));
+                if (restart) hi[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            return;
+        }
         f32x4 ch[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -384,9 +417,14 @@ static int launch_planes_variant(psa_ctx* c, const void* d_planes, const void* d
     const int64_t grid = ((n_tblk + 7) / 8) * 8 * n_mblk;
     PSA_REQUIRE(grid < (1ll << 31) && n_tblk < (1ll << 29) && n_fg < (1ll << 31), "projection grid too large");
     const float qscale = 1.f / (g.vscale * F16x2::P_SCALE);           // powers of two: exact
-    hipLaunchKernelGGL((k1_planes_kernel<MT16, RING>), dim3((unsigned)grid), dim3(512), 0, c->stream,
-                       (const _Float16*)d_planes, (const _Float16*)d_phase, d_q, g.T, g.q_stride, (int)n_fg,
-                       g.A_pad / K1_BA, g.K, n_mblk, (int)n_tblk, qscale);
+    if (n_mblk == 1)
+        hipLaunchKernelGGL((k1_planes_kernel<MT16, RING, true>), dim3((unsigned)grid), dim3(512), 0, c->stream,
+                           (const _Float16*)d_planes, (const _Float16*)d_phase, d_q, g.T, g.q_stride, (int)n_fg,
+                           g.A_pad / K1_BA, g.K, n_mblk, (int)n_tblk, qscale);
+    else
+        hipLaunchKernelGGL((k1_planes_kernel<MT16, RING, false>), dim3((unsigned)grid), dim3(512), 0, c->stream,
+                           (const _Float16*)d_planes, (const _Float16*)d_phase, d_q, g.T, g.q_stride, (int)n_fg,
+                           g.A_pad / K1_BA, g.K, n_mblk, (int)n_tblk, qscale);
     PSA_HIP_CHECK(hipGetLastError());
     return PSA_OK;
 }
@@ -398,6 +436,7 @@ int launch_k1_planes(psa_ctx* c, const void* d_planes, const void* d_phase, floa
                 "planes kernel needs 32-, 64- or 128-row M blocks");
     PSA_REQUIRE(g.A_pad % (2 * K1_BA) == 0 && g.A_pad > 0, "planes kernel needs the atom axis padded to %d", 2 * K1_BA);
     PSA_REQUIRE(g.vscale > 0.f && n_fg * 16 >= g.T, "planes do not cover the launch");
+    if (g.m_blk == 128 && g.M_pad == 128) return launch_planes_variant<4, PSA_K1P_RING1>(c, d_planes, d_phase, d_q, g, n_fg);
     if (g.m_blk == 128) return launch_planes_variant<4, 3>(c, d_planes, d_phase, d_q, g, n_fg);
     if (g.m_blk == 64) return launch_planes_variant<2, 4>(c, d_planes, d_phase, d_q, g, n_fg);
     return launch_planes_variant<1, 4>(c, d_planes, d_phase, d_q, g, n_fg);
