@@ -242,6 +242,24 @@ def pinned_empty(shape, dtype) -> np.ndarray:
     return _pinned_pool.empty(shape, dtype)
 
 
+_SAMPLE_CACHE = {}
+
+
+def _sample_positions(shape):
+    """(flat positions, the same as per-axis index arrays) of the ~2k elements `_fingerprint` reads of an
+    array of this shape; built once per shape."""
+    hit = _SAMPLE_CACHE.get(shape)
+    if hit is None:
+        size = int(np.prod(shape, dtype=np.int64))
+        lin = np.arange(0, size, max(1, size // 1021), dtype=np.int64)[:1021]
+        if size > 2048:
+            lin = np.concatenate([lin, np.sort(np.random.default_rng(size).integers(0, size, 1021)), [size - 1]])
+        if len(_SAMPLE_CACHE) > 64:
+            _SAMPLE_CACHE.clear()
+        hit = _SAMPLE_CACHE[shape] = (lin, np.unravel_index(lin, shape))
+    return hit
+
+
 class Engine:
     """One HIP context (one GPU, one stream) with trajectory arrays resident in HBM."""
 
@@ -293,7 +311,7 @@ class Engine:
     # -- trajectory residency --------------------------------------------------------
     @staticmethod
     def _fingerprint(a: np.ndarray) -> int:
-        """Hash of ~4k elements spread over the array: catches in-place edits of a resident
+        """Hash of ~2k elements spread over the array: catches in-place edits of a resident
         trajectory (scaling, overwriting, loading new frames into the same buffer) without
         reading it.  Not a proof of equality -- `invalidate()` is the explicit way."""
         if a.size == 0:
@@ -311,11 +329,11 @@ class Engine:
             except OSError:
                 pass
         # an even sweep plus scattered positions (an even stride alone can sit on one column of a
-        # (T, N, 3) or (T, K, 3) array for ever); positions depend on the size only
-        lin = np.arange(0, a.size, max(1, a.size // 4099), dtype=np.int64)[:4099]
-        if a.size > 8192:
-            lin = np.concatenate([lin, np.random.default_rng(a.size).integers(0, a.size, 4099), [a.size - 1]])
-        return hash(a[np.unravel_index(lin, a.shape)].tobytes())     # a gather: never copies the array
+        # (T, N, 3) or (T, K, 3) array for ever); positions depend on the shape only and are kept
+        lin, idx = _sample_positions(a.shape)
+        if a.flags.c_contiguous:
+            return hash(a.reshape(-1)[lin].tobytes())                # a gather: never copies the array
+        return hash(a[idx].tobytes())
 
     def _as_device_layout(self, slot: int, array: np.ndarray) -> np.ndarray:
         """The array as C-contiguous float32.  A converted copy is kept (per slot) while the

@@ -11,7 +11,7 @@ batched rocFFT -> epilogue) through `psa_amd._hip.Engine`.  There is no CPU path
 
 Residency: the first `calculate` uploads the velocity array (positions with
 `use_displacements=True`) to HBM -- projecting the frames of each chunk as it lands -- and later
-calls reuse it.  "The same array" is decided by object identity plus a hash of ~4000 sampled
+calls reuse it.  "The same array" is decided by object identity plus a hash of ~2000 sampled
 elements, so in-place edits are normally noticed; after editing a trajectory array in place call
 `calculator.invalidate()` to be certain (the reference re-reads the array on every call).
 

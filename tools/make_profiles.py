@@ -59,8 +59,13 @@ if src.exists():
         "mfma_pipe_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x effective clock x 1024 SIMDs); effective clock = "
                                "GRBM_GUI_ACTIVE / 8 / kernel time (under the profiler, which clocks lower than a plain run)"},
         indent=1) + "\n")
-src = scratch / f"pmc_{tag}k32.json"
-if src.exists():
-    fetch_write(src, out / f"{tag}_K32_pmc_fetch_write.json", "configuration 3's trajectory, 32 k-points = one rank's k-shard of 8", 32768,
-                65536, 32)
+for n_k, share in ((32, 8), (64, 4)):
+    src = scratch / f"pmc_{tag}k{n_k}.json"
+    if src.exists():
+        fetch_write(src, out / f"{tag}_K{n_k}_pmc_fetch_write.json",
+                    f"configuration 3's trajectory, {n_k} k-points = one rank's k-shard of {share}", 32768, 65536, n_k)
+stats = sorted((scratch / f"prof_{tag}_default").rglob("*kernel_stats.csv"), key=lambda p: p.stat().st_mtime)
+if stats:
+    shutil.copy(stats[-1], out / f"{tag}_C3_default_run_kernel_stats.csv")
+    shutil.copy(scratch / f"prof_{tag}_default_bench.json", out / f"{tag}_C3_default_run_bench.json")
 print("\n".join(sorted(p.name for p in out.glob(f"{tag}_*"))))
