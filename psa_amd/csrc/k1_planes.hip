@@ -35,7 +35,7 @@
 // MFMAs (sched_group_barrier) 14.9 ms -- no schedule moves the launch any more: it is power-limited.
 // 256: no non-temporal policy on the planes of a one-M-block launch    512: running source pointers
 // Timing-only experiments (WRONG results): 128 every V read an L2 hit; 1024 no MFMAs; 2048 the P' tile
-// always stage 0 (L2-hot)
+// always stage 0 (L2-hot); 8192 no LDS fragment reads; 16384 no LDS-DMA in the main loop; 32768 no s_barrier
 #ifndef PSA_K1P_X
 #define PSA_K1P_X 563       // product build: 1 + 2 + 16 + 32 + 512 (64 measured 3 % slower)
 #endif
@@ -160,13 +160,41 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
     E8    a[NP][MT16];
     E8    bs[2][3][NP];                            // B fragments of stage k: bs[k & 1][component][piece]
     f32x4 hi[MT16][3], lo[MT16][3];                // the running MFMA chains / the float32 sums
+    if constexpr ((PSA_K1P_X & 8192) != 0) {       // (timing experiment without LDS reads: operands that are
+        // defined, different from register to register and random-looking, so that the matrix pipe sees the
+        // switching activity of real data -- constant operands would let the chip clock up)
+        auto junk = [&](unsigned salt) {
+            E8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                unsigned h = (unsigned)(lane * 8 + e) * 2654435761u ^ (salt * 40503u + 0x9E3779B9u);
+                h ^= h >> 15;
+                h *= 2246822519u;
+                h ^= h >> 13;
+                v[e] = (_Float16)((float)(int)(h & 0xFFFF) * (1.f / 8.f) - 4096.f);
+            }
+            return v;
+        };
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int mt = 0; mt < MT16; ++mt) a[p][mt] = junk(p * 8 + mt);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                bs[0][c][p] = junk(100 + p * 8 + c);
+                bs[1][c][p] = junk(200 + p * 8 + c);
+            }
+        }
+    }
     auto  read_a_tile = [&](int mt, int slot) {
+        if constexpr ((PSA_K1P_X & 8192) != 0) return;
         const unsigned base = p_lane + slot * C::STAGE_BYTES;
 #pragma unroll
         for (int p = 0; p < NP; ++p)
             a[p][mt] = *reinterpret_cast<lds_cv8*>((const lds_u8*)(size_t)(base + (p * C::M_BLK + mt * 16) * 64));
     };
     auto read_b1 = [&](int par, int slot, int i) {
+        if constexpr ((PSA_K1P_X & 8192) != 0) return;
         bs[par][i >> 1][i & 1] = *reinterpret_cast<lds_cv8*>((const lds_u8*)(size_t)(v_lane + slot * C::STAGE_BYTES + i * 1024));
     };
     auto read_b = [&](int par, int slot) {
@@ -221,7 +249,8 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
         const int      slot1 = slot == C::RING - 1 ? 0 : slot + 1;
         constexpr bool STAGGER = (PSA_K1P_X & 1) != 0, SPREAD_DMA = (PSA_K1P_X & 4) != 0,
                        SPREAD_B = (PSA_K1P_X & 8) != 0, FREE = (PSA_K1P_X & 16) != 0;
-        if constexpr (!SPREAD_DMA) {
+        constexpr bool NO_DMA = (PSA_K1P_X & 16384) != 0;
+        if constexpr (!SPREAD_DMA && !NO_DMA) {
             if (!STAGGER || wh == 0) dma_stage(s + C::RING, slot);
         }
         if constexpr (!SPREAD_B) read_b(par ^ 1, slot1);
@@ -239,14 +268,19 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
             mfma_tile(mt, par, restart);
             if constexpr (!FREE) __builtin_amdgcn_sched_barrier(0);
             read_a_tile(mt, slot1);
-            if constexpr (STAGGER && !SPREAD_DMA) {
+            if constexpr (STAGGER && !SPREAD_DMA && !NO_DMA) {
                 if (mt == (PSA_K1P_POS < 0 ? (MT16 - 1) / 2 : (PSA_K1P_POS < MT16 ? PSA_K1P_POS : MT16 - 1)) && wh == 1)
                     dma_stage(s + C::RING, slot);
             }
             if constexpr (!FREE) __builtin_amdgcn_sched_barrier(0);
         }
         // own blocks of stage s+2 landed (younger batches stay in flight), own LDS reads returned
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((C::RING - 2) * C::BATCH) : "memory");
+        if constexpr ((PSA_K1P_X & 32768) != 0)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((C::RING - 2) * C::BATCH) : "memory");
+        else if constexpr (NO_DMA)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((C::RING - 2) * C::BATCH) : "memory");
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
