@@ -277,8 +277,23 @@ int prepare_phase(psa_ctx* c, const int* d_idx, const ProjGeom& g, bool disp, in
 
 // projection of frames [t_begin, t_begin + t_count) of one group into columns t_begin.. of q
 // (K_local,3,q_stride); the phase table is in place
+static int launch_projection_once(psa_ctx* c, int slot, const int* d_idx, ProjGeom g, bool disp, const PlaneSet* ps, float2* d_q,
+                                  int64_t q_stride, int64_t t_begin, int64_t t_count);
+
 int launch_projection(psa_ctx* c, int slot, const int* d_idx, ProjGeom g, bool disp, const PlaneSet* ps, float2* d_q,
                       int64_t q_stride, int64_t t_begin, int64_t t_count) {
+    // PSA_DEBUG_REPEAT_K1=n (diagnostics, tools/short_loop_timing.py): the same launch n times back to back,
+    // each timed on its own (psa_k1_stats) -- the result is that of one launch
+    static const int reps = [] {
+        const char* e = std::getenv("PSA_DEBUG_REPEAT_K1");
+        return e ? std::max(1, std::atoi(e)) : 1;
+    }();
+    for (int r = 0; r < reps; ++r) PSA_TRY(launch_projection_once(c, slot, d_idx, g, disp, ps, d_q, q_stride, t_begin, t_count));
+    return PSA_OK;
+}
+
+static int launch_projection_once(psa_ctx* c, int slot, const int* d_idx, ProjGeom g, bool disp, const PlaneSet* ps, float2* d_q,
+                                  int64_t q_stride, int64_t t_begin, int64_t t_count) {
     const DataSlot& s = c->slot[slot];
     PSA_REQUIRE(t_begin >= 0 && t_count > 0 && t_begin + t_count <= s.T && q_stride >= t_begin + t_count,
                 "frame range [%lld,%lld) outside the slot", (long long)t_begin, (long long)(t_begin + t_count));
