@@ -170,6 +170,41 @@ def test_calculate_sym_matches_reference_golden(case, golden, trajs, engine):
     assert rel_max(plain.sed, sed.sed) <= 2e-6
 
 
+def test_folded_list_projected_in_two_shards_then_mapped(golden, trajs, engine):
+    """What a sharded run does on each rank, on one GPU: the caller folds the list (`k_pairs`),
+    projects the unique vectors as two blocks of slab rows, installs the k map (`psa_sed_set_kmap`) and
+    finalizes -- complex and intensity results equal the reference's, which computed all 36 vectors."""
+    from psa_amd import _hip
+    d = trajs["a"]
+    mean = O.mean_positions(d["positions"])
+    engine.ensure_resident(_hip.SLOT_VELOCITIES, d["velocities"])
+    T = d["velocities"].shape[0]
+    for name, groups, flags in (("s_grid_xy_6x6_coh", None, 0),
+                                ("s_grid_xy_6x6_inc", [np.flatnonzero(d["types"] == 1), np.flatnonzero(d["types"] == 2)],
+                                 _hip.F_INTENSITY)):
+        vecs = golden[f"{name}/k_vecs"]
+        kmap, unique = _hip.k_pairs(vecs)
+        assert len(unique) == 18
+        u = vecs[unique]
+        engine.project(_hip.SLOT_VELOCITIES, mean, u[:11], groups, flags, K_total=18, k_offset=0)
+        engine.project(_hip.SLOT_VELOCITIES, mean, u[11:], groups, flags, K_total=18, k_offset=11)
+        with pytest.raises(_hip.PsaHipError):
+            engine.finalize(T, 36, bool(flags))                   # 18 rows until the map is installed
+        with pytest.raises(_hip.PsaHipError):
+            engine.set_kmap(np.full(36, 18, np.uint32))           # row 18 does not exist
+        engine.set_kmap(kmap)
+        if flags:
+            got = engine.finalize(T, 36, True)
+            assert rel_max(got, golden[f"{name}/intensity"]) <= TOL
+        else:
+            got, inten = engine.finalize(T, 36, False, with_intensity=True)
+            assert rel_max(got[::C.WIDE_SED_STRIDE], golden[f"{name}/sed_rows"]) <= TOL
+            assert rel_max(inten, golden[f"{name}/intensity"]) <= TOL
+            np.testing.assert_allclose(inten, np.sum(np.abs(got) ** 2, axis=-1), rtol=5e-6)
+            phase = engine.result_chiral_phase(T, 36, 0, 1)        # the other result_* calls see 36 columns too
+            assert phase.shape == (T, 36)
+
+
 def test_lists_without_pairs_are_projected_whole(golden, engine):
     """k_fixed != 0: no vector's negation is in the grid -- nothing folds (the shortcut must not be
     taken); same for a k-path from Gamma outwards."""
