@@ -111,6 +111,10 @@ def load_library() -> C.CDLL:
             raise PsaHipError(
                 f"{path} not found: build it with `make -C psa_amd/csrc` (needs hipcc, gfx950). "
                 "psa_amd has no CPU fallback.")
+        # multi-process runs (psa_amd/dist.py): the host driver of this pool supports dmabuf IPC only, and the
+        # HSA runtime reads this when the first HIP call initialises it -- so it is set before the library
+        # (and with it HIP) is loaded; a launcher's own setting wins
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         lib = C.CDLL(str(path))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the .so lacks a symbol

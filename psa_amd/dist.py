@@ -338,8 +338,9 @@ class KShardGroup:
         self.transport_error = None          # why RCCL could not be used (transport == "host")
         if self.nranks > 1:
             # the host driver of this pool supports dmabuf IPC only: without this RCCL's peer-memory
-            # exchange fails with "hipIpcGetMemHandle: invalid argument" (must be set before the
-            # communicator forms; a launcher's own setting wins)
+            # exchange fails with "hipIpcGetMemHandle: invalid argument".  `_hip.load_library` sets it
+            # before HIP initialises (where the HSA runtime reads it); repeated here for engines that
+            # bind the library some other way and for RCCL's own child helpers.  A launcher's setting wins.
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             uid = engine.new_unique_id() if self.rank == 0 else None
             uid = exchange.broadcast(uid, 0)
