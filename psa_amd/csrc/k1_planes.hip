@@ -36,6 +36,8 @@
 // 256: no non-temporal policy on the planes of a one-M-block launch    512: running source pointers
 // Timing-only experiments (WRONG results): 128 every V read an L2 hit; 1024 no MFMAs; 2048 the P' tile
 // always stage 0 (L2-hot); 8192 no LDS fragment reads; 16384 no LDS-DMA in the main loop; 32768 no s_barrier
+// Operand-order experiments (results stay right): 65536 / 131072 / 262144, see mfma_tile / mfma_stage_ordered --
+// 1.3 % between the best and the worst order: not a lever (profiles/r3_k1_experiments.txt)
 #ifndef PSA_K1P_X
 #define PSA_K1P_X 563       // product build: 1 + 2 + 16 + 32 + 512 (64 measured 3 % slower)
 #endif
@@ -231,6 +233,28 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
             return;
         }
         f32x4 ch[3];
+        if constexpr ((PSA_K1P_X & 65536) != 0) {
+            // experiment: every MFMA differs from its predecessor in ONE operand register (the component
+            // order snakes: up, down, up within a row tile, mirrored on odd row tiles); the order of the
+            // three terms of a chain is kept
+            const bool up = (mt & 1) == 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = up ? i : 2 - i;
+                ch[c] = PR::mma(a[1][mt], bs[par][c][0], restart ? f32x4{0.f, 0.f, 0.f, 0.f} : hi[mt][c]);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = up ? 2 - i : i;
+                ch[c] = PR::mma(a[0][mt], bs[par][c][1], ch[c]);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = up ? i : 2 - i;
+                hi[mt][c] = PR::mma(a[0][mt], bs[par][c][0], ch[c]);
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             ch[c] = PR::mma(a[1][mt], bs[par][c][0], restart ? f32x4{0.f, 0.f, 0.f, 0.f} : hi[mt][c]);
@@ -238,6 +262,35 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
         for (int c = 0; c < 3; ++c) ch[c] = PR::mma(a[0][mt], bs[par][c][1], ch[c]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) hi[mt][c] = PR::mma(a[0][mt], bs[par][c][0], ch[c]);
+    };
+    // experiments 131072 / 262144: all 36 MFMAs of a stage in one block, term by term over the twelve
+    // (row tile, component) pairs -- 131072: snake order, one operand register changes per MFMA;
+    // 262144: diagonal order, both change every time.  Same instructions, same reads (all behind the block).
+    auto mfma_stage_ordered = [&](int par, bool restart, bool snake) {
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                int mt, c;
+                if (snake) {
+                    mt = j / 3;
+                    c = (mt & 1) ? 2 - j % 3 : j % 3;
+                    if (term == 1) {             // walk back so that phase B ends where phase C starts
+                        mt = 3 - mt;
+                        c = 2 - c;
+                    }
+                } else {
+                    mt = j % 4;
+                    c = (j + j / 4) % 3;
+                }
+                if (term == 0)
+                    hi[mt][c] = PR::mma(a[1][mt], bs[par][c][0], restart ? f32x4{0.f, 0.f, 0.f, 0.f} : hi[mt][c]);
+                else if (term == 1)
+                    hi[mt][c] = PR::mma(a[0][mt], bs[par][c][1], hi[mt][c]);
+                else
+                    hi[mt][c] = PR::mma(a[0][mt], bs[par][c][0], hi[mt][c]);
+            }
+        }
     };
     // One stage: slot holds stage s (in registers already), slot1 stage s+1 (landed).  The DMA of
     // stage s+RING goes into slot; the B fragments of stage s+1 are read at the top, each row tile's
@@ -255,6 +308,19 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
         }
         if constexpr (!SPREAD_B) read_b(par ^ 1, slot1);
         if constexpr (!FREE) __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((PSA_K1P_X & (131072 | 262144)) != 0 && MT16 == 4) {
+            mfma_stage_ordered(par, restart, (PSA_K1P_X & 131072) != 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT16; ++mt) {
+                read_a_tile(mt, slot1);
+                if constexpr (STAGGER && !NO_DMA) {
+                    if (mt == 1 && wh == 1) dma_stage(s + C::RING, slot);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((C::RING - 2) * C::BATCH) : "memory");
+            return;
+        }
 #pragma unroll
         for (int mt = 0; mt < MT16; ++mt) {
             if constexpr (SPREAD_B) {
