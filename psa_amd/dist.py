@@ -336,6 +336,10 @@ class KShardGroup:
         self.fold_pairs = True               # PSA_OPT_FOLD_PAIRS across ranks
         self._slice = None                   # (weakref to the whole array, frame range, the slice view)
         self.transport_error = None          # why RCCL could not be used (transport == "host")
+        if self.nranks > 1 and mode != "k" and hasattr(engine, "set_option"):
+            # a frame-sharded slot holds T/n frames while the FFT runs over all T: the plan primed from
+            # the slot's own length (PSA_OPT_FFT_PRIME) would be compiled for nothing
+            engine.set_option(_hip.OPT_FFT_PRIME, 0)
         if self.nranks > 1:
             # the host driver of this pool supports dmabuf IPC only: without this RCCL's peer-memory
             # exchange fails with "hipIpcGetMemHandle: invalid argument".  `_hip.load_library` sets it
