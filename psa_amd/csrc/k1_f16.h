@@ -121,6 +121,16 @@ __device__ __forceinline__ void lds_dma16_group(const void* sbase, unsigned voff
     }
 #undef PSA_DMA_ASM
 }
+// one piece of such a group on its own (instruction offset OFF applied to the global and the LDS address)
+template <int OFF, bool NT = false>
+__device__ __forceinline__ void lds_dma16_at(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+    static_assert(OFF >= 0 && OFF <= 3072 && OFF % 1024 == 0, "instruction offsets reach 4095");
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    if constexpr (NT)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3 nt" ::"v"(voff), "s"(sbase), "s"(dst), "n"(OFF) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(sbase), "s"(dst), "n"(OFF) : "memory");
+}
 // 12 bytes per lane, landing at dst + lane * 16
 __device__ __forceinline__ void lds_dma12(const void* g, unsigned lds_byte_addr) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);

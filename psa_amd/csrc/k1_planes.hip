@@ -38,6 +38,7 @@
 // always stage 0 (L2-hot); 8192 no LDS fragment reads; 16384 no LDS-DMA in the main loop; 32768 no s_barrier
 // Operand-order experiments (results stay right): 65536 / 131072 / 262144, see mfma_tile / mfma_stage_ordered --
 // 1.3 % between the best and the worst order: not a lever (profiles/r3_k1_experiments.txt)
+// 524288: a wavefront's DMA pieces issued one by one, spread over the stage (no gain either)
 #ifndef PSA_K1P_X
 #define PSA_K1P_X 563       // product build: 1 + 2 + 16 + 32 + 512 (64 measured 3 % slower)
 #endif
@@ -152,6 +153,23 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
         } else {
 #pragma unroll
             for (int i = 0; i < C::BATCH; ++i) dma_piece(i, st, slot);
+        }
+    };
+
+    // bit 524288 (experiment): the BATCH pieces of a wavefront issued one by one, spread over the stage
+    // (running pointers advance behind the last piece)
+    auto dma_one = [&](auto i_c, int slot) {
+        constexpr int  i = decltype(i_c)::value;
+        const unsigned dst = lds0 + slot * C::STAGE_BYTES;
+        if constexpr (i < C::P_DMA) {
+            lds_dma16_at<1024 * i>(p_next, p_voff, dst + 1024 * pw);
+        } else {
+            lds_dma16_at<1024 * (i - C::P_DMA), NT_V && (PSA_K1P_X & 256) == 0>(
+                v_next, v_voff, dst + C::P_STAGE_BYTES + wf * C::V_GROUP_BYTES + 1024 * (wh * C::V_DMA));
+        }
+        if constexpr (i == C::BATCH - 1) {
+            p_next += C::P_STAGE_BYTES;
+            v_next += C::V_GROUP_BYTES;
         }
     };
 
@@ -303,7 +321,10 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
         constexpr bool STAGGER = (PSA_K1P_X & 1) != 0, SPREAD_DMA = (PSA_K1P_X & 4) != 0,
                        SPREAD_B = (PSA_K1P_X & 8) != 0, FREE = (PSA_K1P_X & 16) != 0;
         constexpr bool NO_DMA = (PSA_K1P_X & 16384) != 0;
-        if constexpr (!SPREAD_DMA && !NO_DMA) {
+        constexpr bool SPREAD_RP = (PSA_K1P_X & 524288) != 0 && MT16 == 4 && C::BATCH == 5;
+        if constexpr (SPREAD_RP) {
+            dma_one(std::integral_constant<int, 0>{}, slot);
+        } else if constexpr (!SPREAD_DMA && !NO_DMA) {
             if (!STAGGER || wh == 0) dma_stage(s + C::RING, slot);
         }
         if constexpr (!SPREAD_B) read_b(par ^ 1, slot1);
@@ -334,7 +355,13 @@ k1_planes_kernel(const _Float16* __restrict__ planes, const _Float16* __restrict
             mfma_tile(mt, par, restart);
             if constexpr (!FREE) __builtin_amdgcn_sched_barrier(0);
             read_a_tile(mt, slot1);
-            if constexpr (STAGGER && !SPREAD_DMA && !NO_DMA) {
+            if constexpr (SPREAD_RP) {
+                if (mt == 0) dma_one(std::integral_constant<int, 1>{}, slot);
+                if (mt == 1) dma_one(std::integral_constant<int, 2>{}, slot);
+                if (mt == 2) dma_one(std::integral_constant<int, 3>{}, slot);
+                if (mt == 3) dma_one(std::integral_constant<int, 4>{}, slot);
+            }
+            if constexpr (STAGGER && !SPREAD_DMA && !NO_DMA && !SPREAD_RP) {
                 if (mt == (PSA_K1P_POS < 0 ? (MT16 - 1) / 2 : (PSA_K1P_POS < MT16 ? PSA_K1P_POS : MT16 - 1)) && wh == 1)
                     dma_stage(s + C::RING, slot);
             }
