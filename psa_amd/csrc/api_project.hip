@@ -65,8 +65,8 @@ void fold_pairs(const float* k, int64_t K, std::vector<int32_t>* kmap, std::vect
     }
 }
 
-// the list the projection runs on when folding pays: *uniq_k receives the unique vectors and the k map
-// is left in c->kmap (installed by install_kmap after begin_result); false = project the list as it is
+// the list the projection runs on when folding pays: *uniq_k receives the vectors to project and *kmap
+// the k map (the caller installs it with install_kmap after begin_result); false = project the list as it is
 static bool fold_k_list(psa_ctx* c, const float* k, int64_t K, std::vector<float>* uniq_k, std::vector<int32_t>* kmap) {
     if (!c->opt_fold_pairs || K < 2 || K >= (1ll << 30)) return false;
     std::vector<int32_t> uidx;
