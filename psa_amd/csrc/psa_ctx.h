@@ -228,6 +228,7 @@ struct psa_ctx {
     psa::FftPlan primed;
     int64_t      primed_T = 0;
     int64_t      opt_fft_prime = 1;
+    int64_t      opt_k1_loader_waves = 0;       // PSA_OPT_K1_LOADER_WAVES (k1_planes_lw.hip)
 
     psa::TimingState timing;
     double oneoff_ms[4] = {0, 0, 0, 0};   // host wall clock of work done once: rocFFT plan builds, magnitude passes,
@@ -286,6 +287,9 @@ int    launch_split_planes(psa_ctx* c, const float* d_x, const float* d_mean, co
                            int64_t N_tot, int n_g, int A_pad, float vscale);
 int    launch_k1_planes(psa_ctx* c, const void* d_planes, const void* d_phase, float2* d_q, const ProjGeom& g,
                         int64_t n_fg);
+// --- k1_planes_lw.hip (the same with dedicated loader wavefronts; 128-row M blocks)
+int    launch_k1_planes_lw(psa_ctx* c, const void* d_planes, const void* d_phase, float2* d_q, const ProjGeom& g,
+                           int64_t n_fg);
 
 // --- k2_epilogue.hip
 int launch_dft_bin(psa_ctx* c, const float2* d_q, int64_t T, int64_t bin, float2* d_out3);

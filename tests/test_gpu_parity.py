@@ -205,6 +205,35 @@ def test_folded_list_projected_in_two_shards_then_mapped(golden, trajs, engine):
             assert phase.shape == (T, 36)
 
 
+@pytest.mark.parametrize("name", ["w_coh_all_k40", "w_coh_all_k140", "w_idx_list_k140", "w_displacements_k40",
+                                  "w_large_phase_k140", "w_inc_types_nested_k140", "s_grid_xy_20x20"])
+def test_loader_wavefront_form_of_the_planes_kernel(name, golden, trajs, engine):
+    """PSA_OPT_K1_LOADER_WAVES: 128-row M blocks projected by k1_planes_lw_kernel (12 wavefronts per
+    workgroup, 4 of them issue all LDS-DMA, component-major MFMAs, 4-slot ring) -- held to the same
+    REFERENCE outputs as the default form, and to the default form itself (same products, same
+    8-stage folds: the sums differ only in the order of the three terms' accumulation)."""
+    from psa_amd import _hip
+    case = next(c for c in C.CALC_WIDE_CASES + C.CALC_SYM_CASES if c["name"] == name)
+    d = trajs[case["traj"]]
+    calc = _calc(d, engine, **case.get("ctor", {}))
+    mags, vecs = golden[f"{name}/k_mags"], golden[f"{name}/k_vecs"]
+    kw = C.realise_kw(case.get("kw", {}))
+    engine.set_option(_hip.OPT_PLANES_EAGER, 1)                      # index lists get their planes at once
+    try:
+        plain = calc.calculate(mags, vecs, **kw)
+        engine.timings()
+        engine.set_option(_hip.OPT_K1_LOADER_WAVES, 1)
+        got = calc.calculate(mags, vecs, **kw)
+        assert engine.timings()["project"] > 0
+    finally:
+        engine.set_option(_hip.OPT_K1_LOADER_WAVES, 0)
+        engine.set_option(_hip.OPT_PLANES_EAGER, 0)
+    assert got.sed.shape == tuple(golden[f"{name}/sed_shape"])
+    assert rel_max(got.sed[::C.WIDE_SED_STRIDE], golden[f"{name}/sed_rows"]) <= TOL
+    assert rel_max(got.intensity if got.is_complex else got.sed, golden[f"{name}/intensity"]) <= TOL
+    assert rel_max(got.sed, plain.sed) <= 1e-6
+
+
 def test_lists_without_pairs_are_projected_whole(golden, engine):
     """k_fixed != 0: no vector's negation is in the grid -- nothing folds (the shortcut must not be
     taken); same for a k-path from Gamma outwards."""
