@@ -152,6 +152,12 @@ int psa_data_fill_synthetic(psa_ctx* ctx, int slot, uint64_t seed, int64_t t_off
  * bit-identical to np.mean(positions, axis=0, dtype=np.float32) (sed_calculator.py:205). */
 int psa_mean_positions(psa_ctx* ctx, int slot, float* mean_host /* (N,3) */);
 
+/* The same mean for an array that stays on the host (velocity mode does not upload positions):
+ * columns split over `threads` host threads (0 = up to 16), each a sequential float32 chain over the
+ * frames like NumPy's -- bit-identical to np.mean(x, axis=0, dtype=np.float32), one pass at memory
+ * bandwidth.  No context, no GPU. */
+int psa_host_mean_frames(const float* x /* (T, cols) */, int64_t T, int64_t cols, float* mean_out, int threads);
+
 /* ---- the hot path -------------------------------------------------------
  * psa_sed_project: for each of the G atom groups, for the K_local k-vectors given,
  *     P[k,a]   = exp(i * (k . mean_pos[idx[a]]))            float32 FMA chain + sincos

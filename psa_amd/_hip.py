@@ -54,6 +54,7 @@ SIGNATURES = {
     "psa_data_fill_synthetic": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_int64, C.c_int, _f32p, _i32p,
                                           _f32p, _f32p, _f32p, _f32p]),
     "psa_mean_positions": (C.c_int, [_ctx, C.c_int, _f32p]),
+    "psa_host_mean_frames": (C.c_int, [_f32p, C.c_int64, C.c_int64, _f32p, C.c_int]),
     "psa_sed_project": (C.c_int, [_ctx, C.c_int, _f32p, _f32p, C.c_int64, C.c_int64, C.c_int64,
                                   _i32p, _i64p, C.c_int32, C.c_int32]),
     "psa_sed_project_upload": (C.c_int, [_ctx, C.c_int, _f32p, C.c_int64, C.c_int64, _f32p, _f32p, C.c_int64,
@@ -158,6 +159,17 @@ def k_pairs(k_vectors):
     _check(load_library().psa_k_pairs(_f32(kv), K, kmap.ctypes.data_as(_i32p), uidx.ctypes.data_as(_i32p), C.byref(n)),
            "psa_k_pairs")
     return kmap.view(np.uint32), uidx[:n.value].copy()
+
+
+def host_mean_frames(x: np.ndarray, threads: int = 0) -> np.ndarray:
+    """np.mean(x, axis=0, dtype=np.float32) of a C-contiguous float32 (T, ...) array, bit for bit, on
+    several host threads (psa_host_mean_frames)."""
+    if x.dtype != np.float32 or not x.flags.c_contiguous or x.ndim < 2 or x.shape[0] < 1 or x.size == 0:
+        raise ValueError("host_mean_frames needs a non-empty C-contiguous float32 array")
+    out = np.empty(x.shape[1:], np.float32)
+    cols = int(np.prod(x.shape[1:], dtype=np.int64))
+    _check(load_library().psa_host_mean_frames(_f32(x), x.shape[0], cols, _f32(out), int(threads)), "psa_host_mean_frames")
+    return out
 
 
 def pack_groups(groups: Optional[Sequence[np.ndarray]]):

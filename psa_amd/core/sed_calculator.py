@@ -127,6 +127,11 @@ class SEDCalculator:
         if self.use_displacements and not frame_sharded:
             self.engine.ensure_resident(_hip.SLOT_POSITIONS, pos)
             mean = self.engine.mean_positions(_hip.SLOT_POSITIONS)
+        elif (isinstance(pos, np.ndarray) and pos.dtype == np.float32 and pos.flags.c_contiguous and pos.ndim == 3
+              and pos.nbytes >= (64 << 20)):
+            # velocity mode: the positions stay on the host; a large array is averaged by the library's
+            # host threads -- the same sequential float32 chain per column as np.mean, bit for bit
+            mean = _hip.host_mean_frames(pos)
         else:               # (a frame-sharded rank holds only its own frames in HBM)
             mean = np.mean(pos, axis=0, dtype=np.float32)
         try:

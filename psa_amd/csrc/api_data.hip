@@ -283,6 +283,38 @@ using namespace psa;
 extern "C" {
 
 // ---- trajectory residency ----------------------------------------------------
+// np.mean(x, axis=0, dtype=float32) of a C-contiguous (T, cols) float32 array ON THE HOST, bit for bit
+// (sed_calculator.py:205): NumPy adds the rows one after the other into a float32 row of sums and
+// divides by T in float32 -- every column is its own sequential chain, so the columns are split over
+// threads and each thread streams its share of every row.  One pass at memory bandwidth (a 25.8 GB
+// positions array: ~0.5 s with 8 threads) where the single-threaded NumPy call takes seconds; used in
+// velocity mode, where the positions are not uploaded (displacement mode: mean_over_frames_kernel).
+int psa_host_mean_frames(const float* x, int64_t T, int64_t cols, float* mean_out, int threads) {
+    PSA_REQUIRE(x != nullptr && mean_out != nullptr && T >= 1 && cols >= 1, "bad argument");
+    int n = threads > 0 ? threads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    n = (int)std::min<int64_t>(n, std::max<int64_t>(1, cols / 256));          // at least 1 KiB of every row per thread
+    const float count = (float)T;
+    auto work = [=](int64_t c0, int64_t c1) {
+        std::vector<float> acc((size_t)(c1 - c0), 0.f);
+        float*             a = acc.data();
+        const int64_t      w = c1 - c0;
+        for (int64_t t = 0; t < T; ++t) {
+            const float* row = x + t * cols + c0;
+            for (int64_t j = 0; j < w; ++j) a[j] += row[j];                     // independent chains: vectorises as it stands
+        }
+        for (int64_t j = 0; j < w; ++j) mean_out[c0 + j] = a[j] / count;
+    };
+    std::vector<std::thread> pool;
+    const int64_t            per = (cols + n - 1) / n;
+    for (int i = 1; i < n; ++i) {
+        const int64_t c0 = std::min<int64_t>(cols, i * per), c1 = std::min<int64_t>(cols, c0 + per);
+        if (c1 > c0) pool.emplace_back(work, c0, c1);
+    }
+    work(0, std::min<int64_t>(cols, per));
+    for (auto& t : pool) t.join();
+    return PSA_OK;
+}
+
 int psa_data_alloc(psa_ctx* c, int slot, int64_t T, int64_t N) {
     PSA_TRY(enter(c));
     Guard g(c);

@@ -93,3 +93,38 @@ def test_intensity_comes_with_the_result_once(trajs):
     sed = calc.calculate(mags, vecs)
     assert not hasattr(pickle.loads(pickle.dumps(sed)), "_intensity_snapshot")
     assert not hasattr(copy.deepcopy(sed), "_intensity_snapshot")
+
+
+def test_host_mean_is_numpy_mean_bit_for_bit(tmp_path):
+    """psa_host_mean_frames (the mean of a positions array that stays on the host, velocity mode) against
+    np.mean(axis=0, dtype=float32) -- reference sed_calculator.py:205 -- for every split of the columns
+    over threads, odd shapes, a memory-mapped file; and the calculator takes it for large arrays."""
+    rng = np.random.default_rng(5)
+    for shape in ((1, 5, 3), (7, 1, 3), (3000, 40, 3), (257, 1001, 3)):
+        x = (50 + 3 * rng.standard_normal(shape)).astype(np.float32)
+        for threads in (0, 1, 3, 16):
+            np.testing.assert_array_equal(_hip.host_mean_frames(x, threads), np.mean(x, axis=0, dtype=np.float32))
+    big = (20 + rng.standard_normal((1400, 4096, 3))).astype(np.float32)            # 69 MB: above the calculator's threshold
+    path = tmp_path / "pos.npy"
+    np.save(path, big)
+    mapped = np.load(path, mmap_mode="r")
+    want = np.mean(big, axis=0, dtype=np.float32)
+    np.testing.assert_array_equal(_hip.host_mean_frames(mapped), want)
+    with np.testing.assert_raises(ValueError):
+        _hip.host_mean_frames(big.astype(np.float64))
+    with np.testing.assert_raises(ValueError):
+        _hip.host_mean_frames(big[:, ::2])
+    from psa_amd import SEDCalculator, Trajectory
+    n = big.shape[1]
+    box = np.diag([10.0, 10.0, 10.0]).astype(np.float32)
+    tr = Trajectory(mapped, big, np.ones(n, np.int32),
+                    np.arange(big.shape[0], dtype=np.float32), box, np.diag(box).copy(), np.zeros(3, np.float32), 0.001)
+    calc = SEDCalculator(tr, 1, 1, 1)
+    calls = []
+    real = _hip.host_mean_frames
+    try:
+        _hip.host_mean_frames = lambda x, threads=0: calls.append(x.shape) or real(x, threads)
+        np.testing.assert_array_equal(calc._mean_positions(), want)
+    finally:
+        _hip.host_mean_frames = real
+    assert calls == [big.shape]
