@@ -44,15 +44,32 @@ def _child(cache_dir, prime):
     return json.loads(res.stdout.strip().splitlines()[-1])
 
 
+def _kernels_in(db):
+    """(kernel name, bytes of code) rows of rocFFT's cache file."""
+    import sqlite3
+    con = sqlite3.connect(f"file:{db}?mode=ro", uri=True)
+    try:
+        return sorted(con.execute("SELECT kernel_name, length(code) FROM cache_v1").fetchall())
+    finally:
+        con.close()
+
+
 def test_second_process_finds_the_fft_kernels_compiled(tmp_path):
+    """The gate is functional: the first process leaves its run-time compiled kernels in the per-user
+    cache file, later processes add nothing to it (they found what they needed) and compute the same
+    numbers, with and without the plan primed during the upload.  The timings are printed, not asserted
+    (bench.py reports `first_step.rocfft_plan_build_ms`; measured 58 -> 23 ms, 1.4-1.8 ms primed:
+    profiles/r3_fft_plan_after.txt)."""
     cache = tmp_path / "psa_cache"
     first = _child(cache, 0)                       # compiles, fills the cache file
     db = cache / "rocfft_rtc_cache.db"
     assert db.exists() and db.stat().st_size > 0
+    kernels = _kernels_in(db)
+    assert kernels and all(size > 0 for _, size in kernels)
     second = _child(cache, 0)                      # loads the compiled kernels instead
+    assert _kernels_in(db) == kernels
     third = _child(cache, 1)                       # ... and builds the plan beside the upload
+    assert _kernels_in(db) == kernels              # (the primed one-vector plan uses the same kernels)
     print(f"rocFFT plan build, T = 65536: first process {first['plan_ms']:.1f} ms, second {second['plan_ms']:.1f} ms, "
           f"second with the plan primed during the upload {third['plan_ms']:.1f} ms")
     assert first["checksum"] == second["checksum"] == third["checksum"] > 0
-    assert second["plan_ms"] <= 0.8 * first["plan_ms"]
-    assert third["plan_ms"] <= 20.0
