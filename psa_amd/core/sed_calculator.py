@@ -504,7 +504,7 @@ class SEDCalculator:
         in HBM -- and the amplitude A of the selected (w, k) bin is replayed as
         Re[A exp(i tau - i k r.k_hat)] over one period.  Plotting the input spectrum (the
         reference's optional last step) is outside this package; `plot_dir_ised` is ignored."""
-        mean_pos = np.mean(self.traj.positions, axis=0, dtype=np.float32)
+        mean_pos = self._mean_positions()              # np.mean(positions, axis=0, dtype=float32), cached per array
         kinds = self.traj.types.astype(int)
         n_atoms = self.traj.n_atoms
         k_hat = parse_direction(k_dir_spec)
