@@ -80,10 +80,11 @@ def parse_args(argv=None):
                     help="N > 1: how the calculation is split over the ranks (psa_amd/dist.py)")
     ap.add_argument("--k-points", type=int, default=0,
                     help="override the config's k-point count (diagnostics, e.g. 32 = one rank's shard of C3 on 8 GPUs)")
-    ap.add_argument("--k1", default="auto", choices=["auto", "loaderwaves", "onthefly", "bf16x3", "mfma32"],
+    ap.add_argument("--k1", default="auto", choices=["auto", "loaderwaves", "eightwaves", "onthefly", "bf16x3", "mfma32"],
                     help="projection kernel: auto = 2xf16 split-precision MFMA from cached split planes (product "
                          "default), onthefly = the same arithmetic splitting in the kernel (no plane cache), "
-                         "loaderwaves = auto with the loader-wavefront form of the planes kernel (k1_planes_lw.hip), "
+                         "loaderwaves / eightwaves = auto with the loader-wavefront form of the planes kernel "
+                         "(k1_planes_lw.hip) always / never (auto picks it from 4 M blocks on), "
                          "bf16x3 = 3xbf16 split-precision MFMA, mfma32 = exact-fp32 MFMA")
     ap.add_argument("--even-split", action="store_true",
                     help="N > 1, mode k: give every rank the same number of k-points instead of the root-heavy split")
@@ -324,12 +325,12 @@ def main():
         _hip.load_library()
         engine = _hip.Engine(local_rank % max(1, _hip.device_count()))
     info = engine.device_info()
-    engine.set_k1({"auto": _hip.K1_AUTO, "loaderwaves": _hip.K1_AUTO, "onthefly": _hip.K1_AUTO, "bf16x3": _hip.K1_SPLIT_BF16,
-                   "mfma32": _hip.K1_MFMA32}[args.k1])
+    engine.set_k1({"auto": _hip.K1_AUTO, "loaderwaves": _hip.K1_AUTO, "eightwaves": _hip.K1_AUTO, "onthefly": _hip.K1_AUTO,
+                   "bf16x3": _hip.K1_SPLIT_BF16, "mfma32": _hip.K1_MFMA32}[args.k1])
     if args.k1 == "onthefly":
         engine.set_option(_hip.OPT_PLANES, 0)
-    if args.k1 == "loaderwaves":
-        engine.set_option(_hip.OPT_K1_LOADER_WAVES, 1)
+    if args.k1 in ("loaderwaves", "eightwaves"):
+        engine.set_option(_hip.OPT_K1_LOADER_WAVES, 1 if args.k1 == "loaderwaves" else 0)
     group = dist.KShardGroup(engine, exchange, gather="root", root=0, mode=args.shard)
 
     # host objects only for the k generators / group resolution (no big arrays on the host):
@@ -559,10 +560,11 @@ def main():
                 dtype = "f32 (3xbf16 split MFMA, fp32 accumulate)"
             else:
                 products = 3
-                kernel_name = ("k1_planes_kernel (k-projection from cached split planes, 2xf16 split-precision MFMA, "
-                               "fp32-equivalent)" if args.k1 == "auto"
-                               else "k1_planes_lw_kernel (the same with dedicated loader wavefronts)" if args.k1 == "loaderwaves"
-                               else "k1_pair_kernel (k-projection, 2xf16 split-precision MFMA, fp32-equivalent)")
+                lw = args.k1 == "loaderwaves" or (args.k1 == "auto" and k_launch > 192)      # the library's rule (launch_projection)
+                kernel_name = ("k1_pair_kernel (k-projection, 2xf16 split-precision MFMA, fp32-equivalent)" if args.k1 == "onthefly"
+                               else ("k1_planes_lw_kernel" if lw and k_launch > 32 else "k1_planes_kernel") +
+                               " (k-projection from cached split planes, 2xf16 split-precision MFMA, fp32-equivalent"
+                               + ("; 4 loader + 8 compute wavefronts per workgroup)" if lw and k_launch > 32 else ")"))
                 dtype = "f32 (2xf16 split MFMA, fp32 accumulate)"
             # matrix-core ceiling for the ALGORITHMIC flop: the fp32 MFMA peak for the exact kernel; for a
             # split kernel the dense 16-bit peak over the MFMA products one fp32 product costs (3 or 6)
@@ -654,7 +656,7 @@ def main():
             out["end_to_end"] = end_to_end
 
         solo = world == 1 and real and extras
-        if solo and req["kind"] == "path" and K >= 64 and args.k1 == "auto":
+        if solo and req["kind"] == "path" and K >= 64 and args.k1 in ("auto", "loaderwaves", "eightwaves"):
             # ---- HBM-bound shapes: one rank's share of this k-path under k-sharding on 4 / 8 GPUs ----------
             shards = {}
             for k_dev in (64, 32):

@@ -114,11 +114,14 @@ int         psa_set_k1(psa_ctx* ctx, int selector);     /* PSA_K1_* */
  *                             $PSA_CACHE_DIR | $XDG_CACHE_HOME/psa_amd | $HOME/.cache/psa_amd so that later
  *                             processes load the compiled kernels instead of compiling them again. */
 #define PSA_OPT_FFT_PRIME      5
-/*   PSA_OPT_K1_LOADER_WAVES [0] project 128-row M blocks with the loader-wavefront form of the planes
- *                             kernel (k1_planes_lw.hip: 12 wavefronts per workgroup, 4 of them issue all
- *                             LDS-DMA, 8 only multiply).  Same arithmetic, same results; measured within
- *                             1 % of the default form on every shape (round 3) -- kept as the evidence that
- *                             the launch is bound by power, not by its schedule. */
+/*   PSA_OPT_K1_LOADER_WAVES [2] which form of the planes kernel projects 128-row M blocks: the one whose
+ *                             eight wavefronts both load and multiply (k1_planes.hip), or the one with
+ *                             twelve wavefronts per workgroup of which four issue all LDS-DMA and eight
+ *                             only multiply (k1_planes_lw.hip).  Same arithmetic, same results.
+ *                             0 = never the loader form, 1 = always, 2 = from four M blocks on (more than
+ *                             192 k-vectors), where it measured 1.5-2 % faster (round 3); the two are
+ *                             within 1 % of each other below that -- the launch is bound by power, not by
+ *                             its schedule. */
 #define PSA_OPT_K1_LOADER_WAVES 6
 int         psa_set_option(psa_ctx* ctx, int option, int64_t value);
 /* device name / CU count / HBM bytes of the context's GPU */
