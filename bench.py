@@ -84,7 +84,7 @@ def parse_args(argv=None):
                     help="projection kernel: auto = 2xf16 split-precision MFMA from cached split planes (product "
                          "default), onthefly = the same arithmetic splitting in the kernel (no plane cache), "
                          "loaderwaves / eightwaves = auto with the loader-wavefront form of the planes kernel "
-                         "(k1_planes_lw.hip) always / never (auto picks it from 4 M blocks on), "
+                         "(k1_planes_lw.hip: the default for 128-row M blocks) forced on / off, "
                          "bf16x3 = 3xbf16 split-precision MFMA, mfma32 = exact-fp32 MFMA")
     ap.add_argument("--even-split", action="store_true",
                     help="N > 1, mode k: give every rank the same number of k-points instead of the root-heavy split")
@@ -560,7 +560,7 @@ def main():
                 dtype = "f32 (3xbf16 split MFMA, fp32 accumulate)"
             else:
                 products = 3
-                lw = args.k1 == "loaderwaves" or (args.k1 == "auto" and k_launch > 192)      # the library's rule (launch_projection)
+                lw = args.k1 in ("auto", "loaderwaves")      # the library's rule (launch_projection): 128-row M blocks
                 kernel_name = ("k1_pair_kernel (k-projection, 2xf16 split-precision MFMA, fp32-equivalent)" if args.k1 == "onthefly"
                                else ("k1_planes_lw_kernel" if lw and k_launch > 32 else "k1_planes_kernel") +
                                " (k-projection from cached split planes, 2xf16 split-precision MFMA, fp32-equivalent"

@@ -114,14 +114,12 @@ int         psa_set_k1(psa_ctx* ctx, int selector);     /* PSA_K1_* */
  *                             $PSA_CACHE_DIR | $XDG_CACHE_HOME/psa_amd | $HOME/.cache/psa_amd so that later
  *                             processes load the compiled kernels instead of compiling them again. */
 #define PSA_OPT_FFT_PRIME      5
-/*   PSA_OPT_K1_LOADER_WAVES [2] which form of the planes kernel projects 128-row M blocks: the one whose
- *                             eight wavefronts both load and multiply (k1_planes.hip), or the one with
- *                             twelve wavefronts per workgroup of which four issue all LDS-DMA and eight
- *                             only multiply (k1_planes_lw.hip).  Same arithmetic, same results.
- *                             0 = never the loader form, 1 = always, 2 = from four M blocks on (more than
- *                             192 k-vectors), where it measured 1.5-2 % faster (round 3); the two are
- *                             within 1 % of each other below that -- the launch is bound by power, not by
- *                             its schedule. */
+/*   PSA_OPT_K1_LOADER_WAVES [1] which form of the planes kernel projects 128-row M blocks (more than 32
+ *                             k-vectors): 1 = twelve wavefronts per workgroup of which four issue all
+ *                             LDS-DMA and eight only multiply (k1_planes_lw.hip), 0 = eight wavefronts
+ *                             that both load and multiply (k1_planes.hip; always used for the 64- and
+ *                             32-row blocks of shorter lists).  Same arithmetic, same results; the loader
+ *                             form measured 2-3 % faster on every shape (round 3). */
 #define PSA_OPT_K1_LOADER_WAVES 6
 int         psa_set_option(psa_ctx* ctx, int option, int64_t value);
 /* device name / CU count / HBM bytes of the context's GPU */

@@ -319,10 +319,7 @@ int psa_set_option(psa_ctx* c, int option, int64_t value) {
             return PSA_OK;
         case PSA_OPT_FOLD_PAIRS: c->opt_fold_pairs = value != 0; return PSA_OK;
         case PSA_OPT_FFT_PRIME: c->opt_fft_prime = value != 0; return PSA_OK;
-        case PSA_OPT_K1_LOADER_WAVES:
-            PSA_REQUIRE(value >= 0 && value <= 2, "PSA_OPT_K1_LOADER_WAVES is 0, 1 or 2");
-            c->opt_k1_loader_waves = value;
-            return PSA_OK;
+        case PSA_OPT_K1_LOADER_WAVES: c->opt_k1_loader_waves = value != 0; return PSA_OK;
     }
     set_error("unknown option %d", option);
     return PSA_EINVAL;

@@ -306,10 +306,9 @@ static int launch_projection_once(psa_ctx* c, int slot, const int* d_idx, ProjGe
         PSA_REQUIRE(ps != nullptr && t_begin % 16 == 0, "planes are cut in groups of 16 frames");
         const int64_t fg0 = t_begin / 16;
         const _Float16* pl = ps->buf.as<_Float16>() + (size_t)fg0 * (size_t)(ps->A_pad / K1_BA) * PL_STAGE_ELEMS;
-        // PSA_OPT_K1_LOADER_WAVES: the same kernel with dedicated loader wavefronts (k1_planes_lw.hip) -- by
-        // default from four M blocks on (more than 192 k-vectors), where it measured 1.5-2 % faster; equal below
-        if (g.m_blk == 128 && (c->opt_k1_loader_waves == 1 || (c->opt_k1_loader_waves == 2 && g.M_pad >= 4 * 128)))
-            return launch_k1_planes_lw(c, pl, c->d_phase.ptr, d_q, g, ps->n_fg - fg0);
+        // PSA_OPT_K1_LOADER_WAVES [1]: 128-row M blocks go to the loader-wavefront form of the kernel
+        // (k1_planes_lw.hip; 2-3 % faster than the eight-wavefront form on every shape, round 3); 0 = never
+        if (g.m_blk == 128 && c->opt_k1_loader_waves) return launch_k1_planes_lw(c, pl, c->d_phase.ptr, d_q, g, ps->n_fg - fg0);
         return launch_k1_planes(c, pl, c->d_phase.ptr, d_q, g, ps->n_fg - fg0);
     }
     if (g.split == 2) return launch_k1_pair(c, d_v, c->d_phase.ptr, d_idx, d_q, g);

@@ -144,8 +144,17 @@ k1_planes_lw_kernel(const _Float16* __restrict__ planes, const _Float16* __restr
                 if (c == 2) read_a_tile(mt, slot1);        // behind the tile's last MFMAs of this stage
             }
         }
-        // every fragment read of this stage has returned: the slot may be overwritten two barriers from now
+        // No wait for the fragment reads here.  What this stage read from its OWN slot (B of c = 1, 2) has been
+        // consumed by the MFMAs above, so it has returned; that slot is overwritten right after this barrier.
+        // What it read from the NEXT slot (A, and B of c = 0, of stage s + 1) is consumed by the MFMAs of
+        // stage s + 1 -- behind the compiler's own counted waits -- and that slot is overwritten only after the
+        // barrier that ends stage s + 1.  (The three-slot ring of k1_planes.hip overwrites the next slot at
+        // once and has to wait here.)
+#ifdef PSA_K1LW_WAIT_READS
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+        asm volatile("s_barrier" ::: "memory");
+#endif
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;

@@ -228,7 +228,7 @@ struct psa_ctx {
     psa::FftPlan primed;
     int64_t      primed_T = 0;
     int64_t      opt_fft_prime = 1;
-    int64_t      opt_k1_loader_waves = 2;       // PSA_OPT_K1_LOADER_WAVES (k1_planes_lw.hip): 0 never, 1 always, 2 from 4 M blocks on
+    int64_t      opt_k1_loader_waves = 1;       // PSA_OPT_K1_LOADER_WAVES: 128-row M blocks through k1_planes_lw.hip
 
     psa::TimingState timing;
     double oneoff_ms[4] = {0, 0, 0, 0};   // host wall clock of work done once: rocFFT plan builds, magnitude passes,

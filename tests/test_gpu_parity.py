@@ -223,11 +223,11 @@ def test_loader_wavefront_form_of_the_planes_kernel(name, golden, trajs, engine)
         engine.set_option(_hip.OPT_K1_LOADER_WAVES, 0)               # never: the eight-wavefront form
         plain = calc.calculate(mags, vecs, **kw)
         engine.timings()
-        engine.set_option(_hip.OPT_K1_LOADER_WAVES, 1)               # always (the default takes it from 4 M blocks on)
+        engine.set_option(_hip.OPT_K1_LOADER_WAVES, 1)               # the default: the loader-wavefront form
         got = calc.calculate(mags, vecs, **kw)
         assert engine.timings()["project"] > 0
     finally:
-        engine.set_option(_hip.OPT_K1_LOADER_WAVES, 2)
+        engine.set_option(_hip.OPT_K1_LOADER_WAVES, 1)
         engine.set_option(_hip.OPT_PLANES_EAGER, 0)
     assert got.sed.shape == tuple(golden[f"{name}/sed_shape"])
     assert rel_max(got.sed[::C.WIDE_SED_STRIDE], golden[f"{name}/sed_rows"]) <= TOL
