@@ -206,22 +206,33 @@ k1_split_kernel(const float* __restrict__ V, const __bf16* __restrict__ Pb, cons
         }
         pp += C::P_STAGE_BYTES;
     };
+    // one M block: every byte of the trajectory is read once by this launch -> non-temporal policy
+    // (aux 2, as for the planes in k1_planes.hip); several M blocks re-read it through L2
+    const bool nt = n_mblk == 1;
     auto dma_v = [&](int slot) {
         unsigned char* vd = smem + slot * C::STAGE_BYTES + wn * C::V_WAVE_BYTES;
         if constexpr (GATHER) {
             // the index of this stage was loaded a stage ago; fetch the one after next now
             const int a = atom_dma;
 #pragma unroll
-            for (int j = 0; j < VP; ++j)
-                __builtin_amdgcn_global_load_lds((gbl_void*)(vp[j] + 3 * (int64_t)a),
-                                                 (lds_void*)(vd + j * C::V_PIECE_BYTES), 12, 0, 0);
+            for (int j = 0; j < VP; ++j) {
+                if (nt)
+                    __builtin_amdgcn_global_load_lds((gbl_void*)(vp[j] + 3 * (int64_t)a),
+                                                     (lds_void*)(vd + j * C::V_PIECE_BYTES), 12, 0, 2);
+                else
+                    __builtin_amdgcn_global_load_lds((gbl_void*)(vp[j] + 3 * (int64_t)a),
+                                                     (lds_void*)(vd + j * C::V_PIECE_BYTES), 12, 0, 0);
+            }
             ++dma_count;
             atom_dma = atom_next;
             atom_next = atom_of(dma_count + 1 < n_stage ? dma_count + 1 : n_stage - 1);
         } else {
 #pragma unroll
             for (int j = 0; j < VP; ++j) {
-                __builtin_amdgcn_global_load_lds((gbl_void*)vp[j], (lds_void*)(vd + j * C::V_PIECE_BYTES), 16, 0, 0);
+                if (nt)
+                    __builtin_amdgcn_global_load_lds((gbl_void*)vp[j], (lds_void*)(vd + j * C::V_PIECE_BYTES), 16, 0, 2);
+                else
+                    __builtin_amdgcn_global_load_lds((gbl_void*)vp[j], (lds_void*)(vd + j * C::V_PIECE_BYTES), 16, 0, 0);
                 vp[j] += K1_VROW;
             }
         }
