@@ -210,7 +210,7 @@ int launch_k1_planes_lw(psa_ctx* c, const void* d_planes, const void* d_phase, f
     const int64_t grid = ((n_tblk + 7) / 8) * 8 * n_mblk;
     PSA_REQUIRE(grid < (1ll << 31) && n_tblk < (1ll << 29) && n_fg < (1ll << 31), "projection grid too large");
     const float qscale = 1.f / (g.vscale * F16x2::P_SCALE);           // powers of two: exact
-    if (n_mblk == 1)
+    if (n_mblk == 1)        // (nt with several M blocks: the siblings start to miss -- 38.7 GB fetched instead of 34.4, +2 % time)
         hipLaunchKernelGGL((k1_planes_lw_kernel<true>), dim3((unsigned)grid), dim3(768), 0, c->stream, (const _Float16*)d_planes,
                            (const _Float16*)d_phase, d_q, g.T, g.q_stride, (int)n_fg, g.A_pad / K1_BA, g.K, n_mblk, (int)n_tblk,
                            qscale);
