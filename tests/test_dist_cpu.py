@@ -110,6 +110,8 @@ def _sharded_worker(rank, world, port, backend, gather, results, no_rccl=False, 
     mags, vecs = calc.get_k_path([1, 1, 0], 2.0, 7)               # 7 k-points over 2 ranks: 4 + 3
     if mode.endswith("+grid"):                                    # 4 x 6 grid symmetric about Gamma: 12 pairs
         mags, vecs, _ = calc.get_k_grid("xy", (-2.0, 2.0), (-1.0, 1.0), 4, 6, 0.0)
+    if mode.endswith("+tiny"):                                    # 2 x 3 grid: 6 vectors, 3 distinct +-k
+        mags, vecs, _ = calc.get_k_grid("xy", (-1.0, 1.0), (-0.5, 0.5), 2, 3, 0.0)
     out = {}
     for name, kw in (("coh", {}), ("inc", dict(basis_atom_types=[1, 2], summation_mode="incoherent"))):
         sed = calc.calculate(mags, vecs, **kw)
@@ -205,6 +207,36 @@ def test_two_rank_sharded_grid_projects_each_pair_once(mode, gather):
         assert res[rank]["coh"].shape == ref_c.shape and res[rank]["inc"].shape == ref_i.shape
         assert conftest.rel_max(res[rank]["coh"], ref_c) <= 2e-6
         assert conftest.rel_max(res[rank]["inc"], ref_i) <= 2e-6
+
+
+def test_five_ranks_share_a_folded_grid_with_fewer_vectors_than_ranks():
+    """2 x 3 grid centred on Gamma: 6 k-vectors, 3 distinct +-k, over 5 ranks (two of them get nothing to
+    project) -- k sharding, root gather; the root's result equals the unsharded oracle."""
+    import conftest
+    from oracle import psa_oracle as O
+    world, port = 5, _free_port()
+    ctx = mp.get_context("spawn")
+
+    with ctx.Manager() as mgr:
+        results = mgr.dict()
+        procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, "tcp", "root", results, True, None, "k+tiny"))
+                 for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(180)
+            assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+        res = {r: dict(results[r]) for r in range(world)}
+    with np.load(conftest.GOLDEN / "traj_a.npz") as z:
+        d = {k: z[k] for k in z.files}
+    calc = conftest.make_calculator(dict(d, dt_ps=float(d["dt_ps"]), cells=tuple(int(v) for v in d["cells"])))
+    _, vecs, _ = calc.get_k_grid("xy", (-1.0, 1.0), (-0.5, 0.5), 2, 3, 0.0)
+    ref_c, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], float(d["dt_ps"]), vecs)
+    ref_i, _, _ = O.calculate(d["positions"], d["velocities"], d["types"], float(d["dt_ps"]), vecs,
+                              basis_atom_types=[1, 2], summation_mode="incoherent")
+    assert [res[r]["coh_range"][1] for r in range(world)] == [1, 1, 1, 0, 0] and res[0]["coh_range"][2] == 3
+    assert conftest.rel_max(res[0]["coh"], ref_c) <= 2e-6 and conftest.rel_max(res[0]["inc"], ref_i) <= 2e-6
+    assert all(res[r]["coh"] is None for r in range(1, world))
 
 
 def test_rendezvous_wire_format_round_trips_dicts():
