@@ -413,7 +413,7 @@ def main():
     first_step_s = time.perf_counter() - t0
     oneoff = engine.oneoff_stats()                               # plan build, magnitude pass, plane build
     elapsed, stages_by_rank, (k1_n, k1_ms) = measure(args.steps, max(0, args.warmup - 1))
-    k_off, k_cnt = group.ranges(K, T)
+    _, k_cnt = group.ranges(K, T)
     real = not args.stub_engine
 
     # N > 1: the gathered result against a one-GPU recomputation on rank 0 (default on)
