@@ -232,6 +232,34 @@ def test_first_call_on_a_memory_mapped_cache(fresh_engine, tmp_path):
     np.testing.assert_array_equal(eng.download(0, spec.n_frames - 256, 256), synth.velocities_block(spec, tables, spec.n_frames - 256, 256))
 
 
+@pytest.mark.parametrize("n_atoms, n_frames, n_k, idx", [
+    (77, 150, 37, None), (33, 64, 33, None), (200, 65, 97, "list"), (64, 1000, 129, None), (1000, 96, 300, "list")])
+def test_ragged_shapes_through_both_forms_of_the_planes_kernel(fresh_engine, n_atoms, n_frames, n_k, idx):
+    """Atom counts that are no multiple of 32, frame counts that are no multiple of 64 (or of 16), k-lists
+    that fill their last 128-row M block partly, index lists with duplicates: the loader-wavefront form
+    (default) and the eight-wavefront form of the planes kernel against the oracle, before the FFT."""
+    from psa_amd import _hip
+    eng = fresh_engine
+    pos, vel = _random_traj(n_atoms, n_frames, seed=n_atoms + n_k)
+    mean, kv = O.mean_positions(pos), _kvecs(n_k, seed=n_k)
+    members = None
+    if idx:
+        rng = np.random.default_rng(n_k)
+        members = np.concatenate([rng.permutation(n_atoms)[: n_atoms // 2], [3, 3, n_atoms - 1]]).astype(np.int32)
+    eng.set_option(_hip.OPT_PLANES_EAGER, 1)
+    eng.ensure_resident(0, vel)
+    sel = np.arange(n_atoms) if members is None else members
+    ref = O.project_group(vel[:, sel, :], O.phase_table(kv, mean[sel]))            # (T, K, 3)
+    got = {}
+    for form in (1, 0):
+        eng.set_option(_hip.OPT_K1_LOADER_WAVES, form)
+        eng.debug_project_only(0, mean, kv, members)                               # (builds the planes on first use)
+        got[form] = eng.debug_project_only(0, mean, kv, members).transpose(2, 0, 1)
+        assert rel_max(got[form], ref) < 2e-6, form
+    assert eng.plane_cache()[0] == 1
+    assert rel_max(got[1], got[0]) < 1e-6
+
+
 # ------------------------------------------------------------------ residency rules
 def test_in_place_edits_are_noticed_and_invalidate_is_explicit(fresh_engine, trajs):
     eng = fresh_engine
