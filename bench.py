@@ -80,11 +80,12 @@ def parse_args(argv=None):
                     help="N > 1: how the calculation is split over the ranks (psa_amd/dist.py)")
     ap.add_argument("--k-points", type=int, default=0,
                     help="override the config's k-point count (diagnostics, e.g. 32 = one rank's shard of C3 on 8 GPUs)")
-    ap.add_argument("--k1", default="auto", choices=["auto", "loaderwaves", "eightwaves", "onthefly", "bf16x3", "mfma32"],
+    ap.add_argument("--k1", default="auto", choices=["auto", "wide", "narrow", "loaderwaves", "eightwaves", "onthefly", "bf16x3", "mfma32"],
                     help="projection kernel: auto = 2xf16 split-precision MFMA from cached split planes (product "
                          "default), onthefly = the same arithmetic splitting in the kernel (no plane cache), "
                          "loaderwaves / eightwaves = auto with the loader-wavefront form of the planes kernel "
-                         "(k1_planes_lw.hip: the default for 128-row M blocks) forced on / off, "
+                         "(k1_planes_lw.hip: the default for 128-row M blocks) forced on / off, wide / narrow = auto with the 256-row "
+                         "workgroup tile (k1_planes_wide.hip, lists of more than 64 k-vectors) forced on / off, "
                          "bf16x3 = 3xbf16 split-precision MFMA, mfma32 = exact-fp32 MFMA")
     ap.add_argument("--even-split", action="store_true",
                     help="N > 1, mode k: give every rank the same number of k-points instead of the root-heavy split")
@@ -325,12 +326,14 @@ def main():
         _hip.load_library()
         engine = _hip.Engine(local_rank % max(1, _hip.device_count()))
     info = engine.device_info()
-    engine.set_k1({"auto": _hip.K1_AUTO, "loaderwaves": _hip.K1_AUTO, "eightwaves": _hip.K1_AUTO, "onthefly": _hip.K1_AUTO,
+    engine.set_k1({"auto": _hip.K1_AUTO, "wide": _hip.K1_AUTO, "narrow": _hip.K1_AUTO, "loaderwaves": _hip.K1_AUTO, "eightwaves": _hip.K1_AUTO, "onthefly": _hip.K1_AUTO,
                    "bf16x3": _hip.K1_SPLIT_BF16, "mfma32": _hip.K1_MFMA32}[args.k1])
     if args.k1 == "onthefly":
         engine.set_option(_hip.OPT_PLANES, 0)
     if args.k1 in ("loaderwaves", "eightwaves"):
         engine.set_option(_hip.OPT_K1_LOADER_WAVES, 1 if args.k1 == "loaderwaves" else 0)
+    if args.k1 in ("wide", "narrow"):
+        engine.set_option(_hip.OPT_K1_WIDE, 1 if args.k1 == "wide" else 0)
     group = dist.KShardGroup(engine, exchange, gather="root", root=0, mode=args.shard)
 
     # host objects only for the k generators / group resolution (no big arrays on the host):

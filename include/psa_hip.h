@@ -121,6 +121,11 @@ int         psa_set_k1(psa_ctx* ctx, int selector);     /* PSA_K1_* */
  *                             32-row blocks of shorter lists).  Same arithmetic, same results; the loader
  *                             form measured 2-3 % faster on every shape (round 3). */
 #define PSA_OPT_K1_LOADER_WAVES 6
+/*   PSA_OPT_K1_WIDE       [0] 1 = lists of more than 64 k-vectors are projected in 256-row M blocks
+ *                             (k1_planes_wide.hip: eight wavefronts, a ring of 1-KiB units, 28 KiB of LDS-DMA
+ *                             per 128 rows and stage instead of 40).  Same arithmetic; the float32 fold
+ *                             comes every 10 stages instead of every 8. */
+#define PSA_OPT_K1_WIDE         7
 int         psa_set_option(psa_ctx* ctx, int option, int64_t value);
 /* device name / CU count / HBM bytes of the context's GPU */
 int         psa_device_info(psa_ctx* ctx, char* name, int name_len,

@@ -23,6 +23,7 @@ F_DISPLACEMENTS, F_INTENSITY = 0x1, 0x2
 K1_AUTO, K1_WAVE, K1_MFMA32, K1_SPLIT_BF16 = 0, 1, 2, 3
 OPT_PLANES, OPT_PLANES_BUDGET, OPT_PLANES_EAGER, OPT_PLANES_MIN_K, OPT_FOLD_PAIRS, OPT_FFT_PRIME = 0, 1, 2, 3, 4, 5
 OPT_K1_LOADER_WAVES = 6
+OPT_K1_WIDE = 7
 KMAP_MIRROR = 0x80000000
 ABI_VERSION = 3
 UNIQUE_ID_BYTES = 128

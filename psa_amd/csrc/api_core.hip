@@ -271,7 +271,7 @@ int psa_destroy(psa_ctx* c) {
         if (c->d2h_ready) (void)hipEventDestroy(c->d2h_ready);
         for (DevBuf* b : {&c->d_kvec, &c->d_mean_all, &c->d_idx, &c->d_mean_g, &c->d_phase, &c->d_qwork,
                           &c->d_fft_work, &c->d_tables, &c->d_absmax, &c->d_slab, &c->d_out, &c->d_aux, &c->d_sync,
-                          &c->d_qrows, &c->d_stage, &c->d_bin, &c->d_upload_max, &c->d_kmap, &c->d_cols, &c->d_inten})
+                          &c->d_qrows, &c->d_stage, &c->d_bin, &c->d_upload_max, &c->d_zeros, &c->d_kmap, &c->d_cols, &c->d_inten})
             b->release();
         (void)hipStreamDestroy(c->stream);
     }
@@ -320,6 +320,7 @@ int psa_set_option(psa_ctx* c, int option, int64_t value) {
         case PSA_OPT_FOLD_PAIRS: c->opt_fold_pairs = value != 0; return PSA_OK;
         case PSA_OPT_FFT_PRIME: c->opt_fft_prime = value != 0; return PSA_OK;
         case PSA_OPT_K1_LOADER_WAVES: c->opt_k1_loader_waves = value != 0; return PSA_OK;
+        case PSA_OPT_K1_WIDE: c->opt_k1_wide = value != 0; return PSA_OK;
     }
     set_error("unknown option %d", option);
     return PSA_EINVAL;

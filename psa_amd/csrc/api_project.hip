@@ -224,7 +224,7 @@ int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, const int* d_i
     if (ps && force == 0) {
         g->split = 4;
         g->vscale = ps->vscale;
-        g->m_blk = k1_planes_block_rows((int)K_local);
+        g->m_blk = c->opt_k1_wide && 2 * K_local > 128 ? 256 : k1_planes_block_rows((int)K_local);
         g->A_pad = ps->A_pad;
         g->M_pad = (int)((2 * K_local + g->m_blk - 1) / g->m_blk * g->m_blk);
         return PSA_OK;
@@ -308,6 +308,7 @@ static int launch_projection_once(psa_ctx* c, int slot, const int* d_idx, ProjGe
         const _Float16* pl = ps->buf.as<_Float16>() + (size_t)fg0 * (size_t)(ps->A_pad / K1_BA) * PL_STAGE_ELEMS;
         // PSA_OPT_K1_LOADER_WAVES [1]: 128-row M blocks go to the loader-wavefront form of the kernel
         // (k1_planes_lw.hip; 2-3 % faster than the eight-wavefront form on every shape, round 3); 0 = never
+        if (g.m_blk == 256) return launch_k1_planes_wide(c, pl, c->d_phase.ptr, d_q, g, ps->n_fg - fg0);
         if (g.m_blk == 128 && c->opt_k1_loader_waves) return launch_k1_planes_lw(c, pl, c->d_phase.ptr, d_q, g, ps->n_fg - fg0);
         return launch_k1_planes(c, pl, c->d_phase.ptr, d_q, g, ps->n_fg - fg0);
     }

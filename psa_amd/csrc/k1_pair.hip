@@ -343,8 +343,11 @@ phase_table_f16_kernel(const float* __restrict__ kvec, const float* __restrict__
     }
 }
 
-// (+ 4 stages of a 128-row block as padding: the kernels prefetch up to RING <= 4 stages past an M block's end)
-size_t pf16_table_bytes(int M_pad, int A_pad) { return (size_t)M_pad * A_pad * 2 * F16x2::NP + 4 * F16x2::NP * 128 * K1_BA * 2; }
+// Padding behind the table: the 128-row kernels prefetch up to RING <= 4 stages past an M block's end (and never
+// read them); the 256-row kernel (k1_planes_wide.hip) runs whole periods of 20 stages and MULTIPLIES up to 21
+// stages of whatever follows its last M block by zero planes -- those bytes must be finite float16: zeroed here.
+constexpr size_t PF16_PAD_BYTES = 22 * (size_t)F16x2::NP * 256 * K1_BA * 2;          // 704 KiB
+size_t pf16_table_bytes(int M_pad, int A_pad) { return (size_t)M_pad * A_pad * 2 * F16x2::NP + PF16_PAD_BYTES; }
 
 int launch_phase_table_f16(psa_ctx* c, const float* d_kvec, const float* d_mean_all, const int* d_idx, void* d_phase,
                            const ProjGeom& g) {
@@ -352,6 +355,8 @@ int launch_phase_table_f16(psa_ctx* c, const float* d_kvec, const float* d_mean_
     hipLaunchKernelGGL(phase_table_f16_kernel, grid, dim3(256), 0, c->stream, d_kvec, d_mean_all, d_idx, (_Float16*)d_phase,
                        g.K, g.n_g, g.A_pad, g.M_pad, g.m_blk);
     PSA_HIP_CHECK(hipGetLastError());
+    if (g.m_blk == 256)
+        PSA_HIP_CHECK(hipMemsetAsync((char*)d_phase + (size_t)g.M_pad * g.A_pad * 2 * F16x2::NP, 0, PF16_PAD_BYTES, c->stream));
     return PSA_OK;
 }
 

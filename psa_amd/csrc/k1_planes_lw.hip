@@ -26,6 +26,14 @@
 // Per stage and CU: the same 40 KiB of LDS-DMA, 112 KiB of fragment reads, 288 MFMAs.
 #include "k1_f16.h"
 
+// Timing-only experiment (tools/k1_experiments.sh with KERNEL=k1_planes_lw MACRO=PSA_K1LW_X; results are WRONG):
+//   1 = 28 KiB of LDS-DMA per stage instead of 40 (what a 256-row workgroup tile would need per 128 rows):
+//       each loader skips half of its phase quarter and its last plane piece, the compute wavefronts read
+//       only what was refreshed (row tiles 0, 1 twice; component 2's second piece from component 1)
+//   2 = every stage fetches the bytes of stage 0 (all LDS-DMA served by L2)
+#ifndef PSA_K1LW_X
+#define PSA_K1LW_X 0
+#endif
 
 namespace psa {
 
@@ -39,7 +47,8 @@ k1_planes_lw_kernel(const _Float16* __restrict__ planes, const _Float16* __restr
     constexpr int P_STAGE_BYTES = NP * M_BLK * K1_BA * 2;                   // 16 KiB
     constexpr int V_GROUP_BYTES = PL_STAGE_ELEMS * 2;                       // 6 KiB
     constexpr int STAGE_BYTES = P_STAGE_BYTES + 4 * V_GROUP_BYTES;          // 40 KiB
-    constexpr int BATCH = 10;                                               // LDS-DMA instructions per loader and stage
+    constexpr bool LESS_DMA = (PSA_K1LW_X & 1) != 0;
+    constexpr int  BATCH = LESS_DMA ? 7 : 10;                               // LDS-DMA instructions per loader and stage
     static_assert(RING * STAGE_BYTES == 160 * 1024, "the ring is all of LDS");
     __shared__ __attribute__((aligned(16))) unsigned char smem[RING * STAGE_BYTES];
     const unsigned lds0 = (unsigned)(size_t)(lds_u8*)smem;
@@ -66,11 +75,13 @@ k1_planes_lw_kernel(const _Float16* __restrict__ planes, const _Float16* __restr
         // padding behind the buffers) and never read -- as in k1_planes.hip
         auto dma_stage = [&](int slot) {
             const unsigned dst = lds0 + slot * STAGE_BYTES;
-            lds_dma16_group<4>(p_next, p_voff, dst + 4096 * j);
+            lds_dma16_group<LESS_DMA ? 2 : 4>(p_next, p_voff, dst + 4096 * j);
             lds_dma16_group<3, NT_V>(v_next, v_voff, dst + P_STAGE_BYTES + j * V_GROUP_BYTES);
-            lds_dma16_group<3, NT_V>(v_next, v_voff + 3072, dst + P_STAGE_BYTES + j * V_GROUP_BYTES + 3072);
-            p_next += P_STAGE_BYTES;
-            v_next += V_GROUP_BYTES;
+            lds_dma16_group<LESS_DMA ? 2 : 3, NT_V>(v_next, v_voff + 3072, dst + P_STAGE_BYTES + j * V_GROUP_BYTES + 3072);
+            if constexpr (!(PSA_K1LW_X & 2)) {
+                p_next += P_STAGE_BYTES;
+                v_next += V_GROUP_BYTES;
+            }
         };
         __builtin_amdgcn_s_setprio(2);     // a loader's few instructions go first (priorities 0 and 3 measured the same)
         dma_stage(0);
@@ -103,12 +114,13 @@ k1_planes_lw_kernel(const _Float16* __restrict__ planes, const _Float16* __restr
         const unsigned base = p_lane + slot * STAGE_BYTES;
 #pragma unroll
         for (int p = 0; p < NP; ++p)
-            a[p][mt] = *reinterpret_cast<lds_cv8*>((const lds_u8*)(size_t)(base + (p * M_BLK + mt * 16) * 64));
+            a[p][mt] = *reinterpret_cast<lds_cv8*>((const lds_u8*)(size_t)(base + (p * M_BLK + (LESS_DMA ? mt & 1 : mt) * 16) * 64));
     };
     auto read_b = [&](int buf, int slot, int c) {
 #pragma unroll
         for (int p = 0; p < NP; ++p)
-            bb[buf][p] = *reinterpret_cast<lds_cv8*>((const lds_u8*)(size_t)(v_lane + slot * STAGE_BYTES + (c * NP + p) * 1024));
+            bb[buf][p] = *reinterpret_cast<lds_cv8*>(
+                (const lds_u8*)(size_t)(v_lane + slot * STAGE_BYTES + ((LESS_DMA && c == 2 && p == 1 ? 1 : c) * NP + p) * 1024));
     };
 #pragma unroll
     for (int mt = 0; mt < MT16; ++mt)

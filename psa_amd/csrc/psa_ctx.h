@@ -189,6 +189,7 @@ struct psa_ctx {
     // per-call scratch
     psa::DevBuf d_kvec, d_mean_all, d_idx, d_mean_g, d_phase, d_qwork, d_fft_work, d_tables, d_absmax;
     psa::DevBuf d_upload_max;                 // running largest magnitude of an array being uploaded
+    psa::DevBuf d_zeros;                      // 1 KiB of zeros (k1_planes_wide.hip: planes of the stages past a group's end)
     psa::DevBuf d_qrows, d_stage, d_bin;      // frame sharding: my rows before the FFT / all-to-all landing zone; one DFT bin
 
     // cached split planes (PSA_OPT_PLANES*)
@@ -228,6 +229,7 @@ struct psa_ctx {
     psa::FftPlan primed;
     int64_t      primed_T = 0;
     int64_t      opt_fft_prime = 1;
+    int64_t      opt_k1_wide = 0;               // PSA_OPT_K1_WIDE: 256-row M blocks (k1_planes_wide.hip) for lists of more than 64 k-vectors
     int64_t      opt_k1_loader_waves = 1;       // PSA_OPT_K1_LOADER_WAVES: 128-row M blocks through k1_planes_lw.hip
 
     psa::TimingState timing;
@@ -290,6 +292,10 @@ int    launch_k1_planes(psa_ctx* c, const void* d_planes, const void* d_phase, f
 // --- k1_planes_lw.hip (the same with dedicated loader wavefronts; 128-row M blocks)
 int    launch_k1_planes_lw(psa_ctx* c, const void* d_planes, const void* d_phase, float2* d_q, const ProjGeom& g,
                            int64_t n_fg);
+
+// --- k1_planes_wide.hip (256-row M blocks: k-lists of more than 64 vectors under PSA_OPT_K1_WIDE)
+int    launch_k1_planes_wide(psa_ctx* c, const void* d_planes, const void* d_phase, float2* d_q, const ProjGeom& g,
+                             int64_t n_fg);
 
 // --- k2_epilogue.hip
 int launch_dft_bin(psa_ctx* c, const float2* d_q, int64_t T, int64_t bin, float2* d_out3);
