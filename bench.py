@@ -563,11 +563,15 @@ def main():
                 dtype = "f32 (3xbf16 split MFMA, fp32 accumulate)"
             else:
                 products = 3
-                lw = args.k1 in ("auto", "loaderwaves")      # the library's rule (launch_projection): 128-row M blocks
+                # the library's rules (k1_planes_block_rows, launch_projection): 256-row M blocks where the list fills
+                # an even number of 128-row blocks, else 128-row blocks in the loader-wavefront form
+                wide = args.k1 in ("auto", "wide") and k_launch > 32 and (-(-2 * k_launch // 128)) % 2 == 0
+                lw = not wide and args.k1 in ("auto", "narrow", "wide", "loaderwaves") and k_launch > 32
                 kernel_name = ("k1_pair_kernel (k-projection, 2xf16 split-precision MFMA, fp32-equivalent)" if args.k1 == "onthefly"
-                               else ("k1_planes_lw_kernel" if lw and k_launch > 32 else "k1_planes_kernel") +
+                               else ("k1_planes_wide_kernel" if wide else "k1_planes_lw_kernel" if lw else "k1_planes_kernel") +
                                " (k-projection from cached split planes, 2xf16 split-precision MFMA, fp32-equivalent"
-                               + ("; 4 loader + 8 compute wavefronts per workgroup)" if lw and k_launch > 32 else ")"))
+                               + ("; 256-row x 64-frame workgroup tile, 8 wavefronts)" if wide else
+                                  "; 4 loader + 8 compute wavefronts per workgroup)" if lw else ")"))
                 dtype = "f32 (2xf16 split MFMA, fp32 accumulate)"
             # matrix-core ceiling for the ALGORITHMIC flop: the fp32 MFMA peak for the exact kernel; for a
             # split kernel the dense 16-bit peak over the MFMA products one fp32 product costs (3 or 6)

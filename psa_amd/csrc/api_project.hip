@@ -224,7 +224,7 @@ int make_geom(psa_ctx* c, int slot, int64_t K_local, int64_t n_g, const int* d_i
     if (ps && force == 0) {
         g->split = 4;
         g->vscale = ps->vscale;
-        g->m_blk = c->opt_k1_wide && 2 * K_local > 128 ? 256 : k1_planes_block_rows((int)K_local);
+        g->m_blk = k1_planes_block_rows((int)K_local, c->opt_k1_wide != 0);
         g->A_pad = ps->A_pad;
         g->M_pad = (int)((2 * K_local + g->m_blk - 1) / g->m_blk * g->m_blk);
         return PSA_OK;

@@ -533,7 +533,14 @@ int launch_split_planes(psa_ctx* c, const float* d_x, const float* d_mean, const
 }
 
 // rows per workgroup for a k-list: 128 beyond 32 k-vectors, 64 for 17..32, 32 up to 16
-int k1_planes_block_rows(int K) { return 2 * K <= 32 ? 32 : 2 * K <= 64 ? 64 : 128; }
+// 256-row blocks (k1_planes_wide.hip, 3-6 % faster per row) where they cost no extra rows: an even number of
+// 128-row blocks.  (192 k-vectors = three 128-row blocks would become two 256-row blocks: a third more MFMAs.)
+int k1_planes_block_rows(int K, bool wide) {
+    if (2 * K <= 32) return 32;
+    if (2 * K <= 64) return 64;
+    const int n128 = (2 * K + 127) / 128;
+    return wide && n128 % 2 == 0 ? 256 : 128;
+}
 
 template <int MT16, int RING>
 static int launch_planes_variant(psa_ctx* c, const void* d_planes, const void* d_phase, float2* d_q, const ProjGeom& g,

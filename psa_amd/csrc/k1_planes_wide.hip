@@ -30,10 +30,27 @@
 
 #include "k1_f16.h"
 
+// Schedule experiments (tools/k1_experiments.sh with KERNEL=k1_planes_wide MACRO=PSA_K1W_X; results stay right):
+//   1: chains folded every 20 stages instead of every 10     2: s_setprio 1 for the second row half (waves 4-7)
+//   4: the stages past the group's last one are skipped instead of multiplying zeros
+//   8: the next row tile's A fragments are read before the tile's first MFMA (left alone the compiler reads them behind the third)
+//   PSA_K1W_POS p >= 0: the second row half (waves 4-7, the SIMD partners of 0-3) issues its LDS-DMA behind row tile p
+//   instead of at the top of the stage, where its partner is issuing too
+//   PSA_K1W_LATE p >= 0: (s+2, k=4..5) -- the two units that have two stages to land -- are issued behind row tile p
+#ifndef PSA_K1W_POS
+#define PSA_K1W_POS 1       // product build (-2 %; from row tile 3 on the units arrive late: +5 %, +15 % at tile 5)
+#endif
+#ifndef PSA_K1W_LATE
+#define PSA_K1W_LATE -1
+#endif
+#ifndef PSA_K1W_X
+#define PSA_K1W_X 4       // product build (4 measured -1 %: configuration 3 has 1024 stages = 51 periods + 4)
+#endif
+
 namespace psa {
 
 namespace {
-constexpr int W_M_BLK = 256, W_T_BLK = 64, W_FOLD = 10, W_PERIOD = 20;
+constexpr int W_M_BLK = 256, W_T_BLK = 64, W_FOLD = (PSA_K1W_X & 1) ? 20 : 10, W_PERIOD = 20;
 constexpr int W_STAGE_UNITS = 56, W_RING_UNITS = 160;
 constexpr int W_P_STAGE_BYTES = F16x2::NP * W_M_BLK * K1_BA * 2;        // 32 KiB
 constexpr int W_V_GROUP_BYTES = PL_STAGE_ELEMS * 2;                     // 6 KiB
@@ -164,20 +181,33 @@ k1_planes_wide_kernel(const _Float16* __restrict__ planes, const _Float16* __res
     read_a(I0{}, I0{}, I0{});
 
     // ---- one stage; returns false behind the last one -------------------------------------------------------
+    int  left = n_stage;                                                   // stages to go when the period began
     auto stage = [&](auto s20_c) __attribute__((always_inline)) {
         constexpr int  S20 = decltype(s20_c)::value;
+        if constexpr ((PSA_K1W_X & 4) != 0) {
+            if (left <= S20) return;
+        }
         constexpr bool restart = S20 % W_FOLD == 0, folds = S20 % W_FOLD == W_FOLD - 1;
         using SN = integral_constant<int, (S20 + 1) % W_PERIOD>;
         using SNN = integral_constant<int, (S20 + 2) % W_PERIOD>;
         // stage s-1's units are free: (s+1, k=6), (s+2, k=0..5)
-        dma(SN{}, integral_constant<int, 6>{});
-        dma_range(SNN{}, std::make_integer_sequence<int, 6>{});
+        constexpr int EARLY = PSA_K1W_LATE >= 0 ? 4 : 6;
+        auto issue = [&]() __attribute__((always_inline)) {
+            dma(SN{}, integral_constant<int, 6>{});
+            dma_range(SNN{}, std::make_integer_sequence<int, EARLY>{});
+        };
+        if constexpr (PSA_K1W_POS < 0) {
+            issue();
+        } else {
+            if (wh == 0) issue();
+        }
         auto tile = [&](auto mt_c) __attribute__((always_inline)) {
             constexpr int MTI = decltype(mt_c)::value, cur = MTI & 1;
             if constexpr (MTI < MT - 1)
                 read_a(s20_c, integral_constant<int, (cur ^ 1)>{}, integral_constant<int, MTI + 1>{});
             else
-                read_a(SN{}, integral_constant<int, (cur ^ 1)>{}, I0{});                          // row tile 0 of the next stage (landed: k = 3)
+                read_a(SN{}, integral_constant<int, (cur ^ 1)>{}, I0{});
+            if constexpr ((PSA_K1W_X & 8) != 0) __builtin_amdgcn_sched_barrier(0);      // the reads stay in front of the tile's MFMAs                          // row tile 0 of the next stage (landed: k = 3)
             auto comp = [&](auto c_c) __attribute__((always_inline)) {
                 constexpr int CC = decltype(c_c)::value;
                 f32x4 ch = PR::mma(a[cur][1], bf[CC][0], restart ? f32x4{0.f, 0.f, 0.f, 0.f} : hi[MTI][CC]);
@@ -188,15 +218,28 @@ k1_planes_wide_kernel(const _Float16* __restrict__ planes, const _Float16* __res
             comp(I0{});
             comp(I1{});
             comp(integral_constant<int, 2>{});
+            if constexpr (PSA_K1W_POS >= 0 && MTI == PSA_K1W_POS) {
+                if (wh != 0) issue();
+            }
+            if constexpr (PSA_K1W_LATE >= 0 && MTI == PSA_K1W_LATE) {
+                dma(SNN{}, integral_constant<int, 4>{});
+                dma(SNN{}, integral_constant<int, 5>{});
+            }
             __builtin_amdgcn_sched_barrier(0);     // 232 registers are live by design: nothing moves across a row tile
         };
         [&]<int... Ms>(std::integer_sequence<int, Ms...>) __attribute__((always_inline)) { (tile(integral_constant<int, Ms>{}), ...); }(std::make_integer_sequence<int, MT>{});
         if constexpr (folds) fold();
+        else if constexpr ((PSA_K1W_X & 4) != 0) {
+            if (left == S20 + 1) fold();                                  // the last stage of the group
+        }
         // What this stage read from its own units has been consumed by the MFMAs above (it has returned); the
         // reads still in flight come from stage s+1's units, which nothing overwrites before barrier s+1.
         asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
     };
-    for (int left = n_stage; left > 0; left -= W_PERIOD)
+    if constexpr ((PSA_K1W_X & 2) != 0) {
+        if (wh) __builtin_amdgcn_s_setprio(1);
+    }
+    for (; left > 0; left -= W_PERIOD)
         [&]<int... Ss>(std::integer_sequence<int, Ss...>) __attribute__((always_inline)) { (stage(integral_constant<int, Ss>{}), ...); }(
             std::make_integer_sequence<int, W_PERIOD>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // nothing in flight when LDS is handed on

@@ -229,7 +229,7 @@ struct psa_ctx {
     psa::FftPlan primed;
     int64_t      primed_T = 0;
     int64_t      opt_fft_prime = 1;
-    int64_t      opt_k1_wide = 0;               // PSA_OPT_K1_WIDE: 256-row M blocks (k1_planes_wide.hip) for lists of more than 64 k-vectors
+    int64_t      opt_k1_wide = 1;               // PSA_OPT_K1_WIDE: 256-row M blocks (k1_planes_wide.hip) where the k-list fills them (k1_planes_block_rows)
     int64_t      opt_k1_loader_waves = 1;       // PSA_OPT_K1_LOADER_WAVES: 128-row M blocks through k1_planes_lw.hip
 
     psa::TimingState timing;
@@ -284,7 +284,7 @@ int    launch_k1_pair(psa_ctx* c, const float* d_v, const void* d_phase, const i
                       const ProjGeom& g);
 
 // --- k1_planes.hip ("2 x f16" from cached split planes: every kind of group)
-int    k1_planes_block_rows(int K);
+int    k1_planes_block_rows(int K, bool wide);
 int    launch_split_planes(psa_ctx* c, const float* d_x, const float* d_mean, const int* d_idx, void* d_planes, int64_t T,
                            int64_t N_tot, int n_g, int A_pad, float vscale);
 int    launch_k1_planes(psa_ctx* c, const void* d_planes, const void* d_phase, float2* d_q, const ProjGeom& g,

@@ -233,11 +233,14 @@ def test_first_call_on_a_memory_mapped_cache(fresh_engine, tmp_path):
 
 
 @pytest.mark.parametrize("n_atoms, n_frames, n_k, idx", [
-    (77, 150, 37, None), (33, 64, 33, None), (200, 65, 97, "list"), (64, 1000, 129, None), (1000, 96, 300, "list")])
-def test_ragged_shapes_through_both_forms_of_the_planes_kernel(fresh_engine, n_atoms, n_frames, n_k, idx):
-    """Atom counts that are no multiple of 32, frame counts that are no multiple of 64 (or of 16), k-lists
-    that fill their last 128-row M block partly, index lists with duplicates: the loader-wavefront form
-    (default) and the eight-wavefront form of the planes kernel against the oracle, before the FFT."""
+    (77, 150, 37, None), (33, 64, 33, None), (200, 65, 97, "list"), (64, 1000, 129, None), (1000, 96, 300, "list"),
+    (77, 150, 128, None), (700, 130, 250, "list"), (2000, 64, 65, None)])
+def test_ragged_shapes_through_every_form_of_the_planes_kernel(fresh_engine, n_atoms, n_frames, n_k, idx):
+    """Atom counts that are no multiple of 32 (stage counts that are no multiple of the wide kernel's 20-stage
+    period), frame counts that are no multiple of 64 (or of 16), k-lists that fill their last M block partly,
+    index lists with duplicates: the 256-row form (default where the list fills an even number of 128-row
+    blocks), the loader-wavefront form and the eight-wavefront form of the planes kernel against the oracle,
+    before the FFT."""
     from psa_amd import _hip
     eng = fresh_engine
     pos, vel = _random_traj(n_atoms, n_frames, seed=n_atoms + n_k)
@@ -251,13 +254,14 @@ def test_ragged_shapes_through_both_forms_of_the_planes_kernel(fresh_engine, n_a
     sel = np.arange(n_atoms) if members is None else members
     ref = O.project_group(vel[:, sel, :], O.phase_table(kv, mean[sel]))            # (T, K, 3)
     got = {}
-    for form in (1, 0):
-        eng.set_option(_hip.OPT_K1_LOADER_WAVES, form)
+    for form in ((1, 1), (0, 1), (0, 0)):
+        eng.set_option(_hip.OPT_K1_WIDE, form[0])
+        eng.set_option(_hip.OPT_K1_LOADER_WAVES, form[1])
         eng.debug_project_only(0, mean, kv, members)                               # (builds the planes on first use)
         got[form] = eng.debug_project_only(0, mean, kv, members).transpose(2, 0, 1)
         assert rel_max(got[form], ref) < 2e-6, form
     assert eng.plane_cache()[0] == 1
-    assert rel_max(got[1], got[0]) < 1e-6
+    assert rel_max(got[0, 1], got[0, 0]) < 1e-6 and rel_max(got[1, 1], got[0, 1]) < 1e-6
 
 
 # ------------------------------------------------------------------ residency rules
@@ -523,7 +527,8 @@ def test_very_long_k_lists_are_projected_in_blocks(fresh_engine, monkeypatch):
     whole_inc = eng.finalize(96, 300, True)
     monkeypatch.setenv("PSA_PHASE_TABLE_MIB", "1")               # 1024 atoms x 8 B -> blocks of 128 k-vectors
     eng.project(0, mean, kv)
-    np.testing.assert_array_equal(eng.finalize(96, 300, False), whole)       # same kernels per k-vector
+    # (300 k-vectors at once run in 128-row blocks, blocks of 128 in one 256-row block: the float32 folds differ)
+    assert rel_max(eng.finalize(96, 300, False), whole) <= 2e-6
     eng.project(0, mean, kv, groups, _hip.F_INTENSITY)
     np.testing.assert_allclose(eng.finalize(96, 300, True), whole_inc, rtol=1e-6)
     ref, _, _ = O.calculate(pos, vel, types, 0.002, kv)

@@ -10,7 +10,7 @@ for K in $2; do
     for x in $1; do
       lib=$ROOT/psa_amd/csrc/libpsa_hip.so
       [ "$x" != 0 ] && lib=$OUT/libpsa_hip_x$x.so
-      PSA_HIP_LIBRARY=$lib python "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 6 --warmup 2 --k-points $K 2>/dev/null |
+      PSA_HIP_LIBRARY=$lib python "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 6 --warmup 2 --k-points $K $BENCH_EXTRA 2>/dev/null |
         python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('K=$K round $round variant $x: K1 %.3f ms  frac %.3f (%s)' % (r['avg_launch_ms'], r['frac'], r['bound']))" | tee -a "$res"
     done
   done
