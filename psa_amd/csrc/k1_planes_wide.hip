@@ -20,7 +20,8 @@
 // u = 8 k + w (k = 0..6) of every stage: k = 0..2 are the planes (unit 8 c + 4 p + j = component c, piece p,
 // frame group j: a wavefront copies its own frame group's piece h), k = 3..6 the phase tile in the order
 // the row tiles are consumed (unit 24 + 4 mt + 2 h + p).  Entering stage s (barrier s-1 passed; stage s-1's 56 units are free) a wavefront
-// issues (s+1, k=6) and (s+2, k=0..5); the barrier that ends a stage is preceded by vmcnt(2): everything
+// issues (s+1, k=6) and (s+2, k=0..5) (shipped form: waves 0-3 issue their SIMD partners' units too, PSA_K1W_SOLO);
+// the barrier that ends a stage is preceded by vmcnt(2) (SOLO: 4): everything
 // but (s+2, k=4..5) has landed -- all of stage s+1 and the first 32 units of stage s+2, i.e. its planes
 // and row tiles 0-1, which is what the last row tile of a stage prefetches.  Every unit has at least one
 // stage time (~1.7 us) between issue and first use.  Ring positions repeat every 20 stages (7 blocks of
@@ -42,6 +43,10 @@
 #endif
 #ifndef PSA_K1W_LATE
 #define PSA_K1W_LATE -1
+#endif
+//   PSA_K1W_SOLO 1: the first row half (waves 0-3) issues ALL LDS-DMA -- its own units and its SIMD partner's --, waves 4-7 none
+#ifndef PSA_K1W_SOLO
+#define PSA_K1W_SOLO 1      // product build (-1.8 % against both halves issuing, the second behind row tile 1)
 #endif
 #ifndef PSA_K1W_X
 #define PSA_K1W_X 4       // product build (4 measured -1 %: configuration 3 has 1024 stages = 51 periods + 4)
@@ -103,6 +108,15 @@ k1_planes_wide_kernel(const _Float16* __restrict__ planes, const _Float16* __res
         const int y = 8 * (k - 3) + w, mt = y >> 2, h = (y >> 1) & 1, p = y & 1;
         src[k] = ph0 + 1024 * (p * 16 + h * 8 + mt);                    // image [piece][256 rows][32 atoms]: 1 KiB per row tile
     }
+    // (PSA_K1W_SOLO: the partner's streams, units 8 k + w + 4 -- piece 1 of the same planes, the other half's row tiles)
+    const unsigned char* src2[7];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) src2[k] = pl0 + (size_t)fg * n_stage * W_V_GROUP_BYTES + 1024 * (2 * k + 1);
+#pragma unroll
+    for (int k = 3; k < 7; ++k) {
+        const int y = 8 * (k - 3) + w + 4, mt = y >> 2, h = (y >> 1) & 1, p = y & 1;
+        src2[k] = ph0 + 1024 * (p * 16 + h * 8 + mt);
+    }
     const unsigned dma_voff = 16 * lane;
     int            to_issue = n_stage;                                  // stages whose planes have not been issued yet
     const unsigned wbase = lds0 + 1024 * w;                             // unit 8 k + w of a stage: 1024 w past the block of k
@@ -115,10 +129,18 @@ k1_planes_wide_kernel(const _Float16* __restrict__ planes, const _Float16* __res
             // planes come from a block of zeros, their phase tile is whatever follows (finite float16)
             w_dma<OFF, NT_V>(to_issue > 0 ? src[KK] : reinterpret_cast<const unsigned char*>(zeros), dma_voff, wbase);
             src[KK] += W_V_GROUP_BYTES;
+            if constexpr (PSA_K1W_SOLO != 0) {
+                w_dma<OFF + 4096, NT_V>(to_issue > 0 ? src2[KK] : reinterpret_cast<const unsigned char*>(zeros), dma_voff, wbase);
+                src2[KK] += W_V_GROUP_BYTES;
+            }
             if constexpr (KK == 2) --to_issue;
         } else {
             w_dma<OFF, false>(src[KK], dma_voff, wbase);
             src[KK] += W_P_STAGE_BYTES;
+            if constexpr (PSA_K1W_SOLO != 0) {
+                w_dma<OFF + 4096, false>(src2[KK], dma_voff, wbase);
+                src2[KK] += W_P_STAGE_BYTES;
+            }
         }
     };
     using std::integral_constant;
@@ -172,9 +194,12 @@ k1_planes_wide_kernel(const _Float16* __restrict__ planes, const _Float16* __res
     // ---- prologue: stage 0 (k = 0..6) and stage 1 (k = 0..5) ----------------------------------------------
     using I0 = integral_constant<int, 0>;
     using I1 = integral_constant<int, 1>;
-    dma_range(I0{}, std::make_integer_sequence<int, 7>{});
-    dma_range(I1{}, std::make_integer_sequence<int, 6>{});
-    asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");          // stage 0 and the first 32 units of stage 1 landed
+    constexpr int PENDING = PSA_K1W_SOLO ? 4 : 2;                          // DMA instructions a barrier leaves in flight per issuing wavefront
+    if (PSA_K1W_SOLO == 0 || wh == 0) {
+        dma_range(I0{}, std::make_integer_sequence<int, 7>{});
+        dma_range(I1{}, std::make_integer_sequence<int, 6>{});
+    }
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PENDING) : "memory");   // stage 0 and the first 32 units of stage 1 landed
     read_b(I0{}, I0{});
     read_b(I0{}, I1{});
     read_b(I0{}, integral_constant<int, 2>{});
@@ -196,7 +221,9 @@ k1_planes_wide_kernel(const _Float16* __restrict__ planes, const _Float16* __res
             dma(SN{}, integral_constant<int, 6>{});
             dma_range(SNN{}, std::make_integer_sequence<int, EARLY>{});
         };
-        if constexpr (PSA_K1W_POS < 0) {
+        if constexpr (PSA_K1W_SOLO != 0) {
+            if (wh == 0) issue();
+        } else if constexpr (PSA_K1W_POS < 0) {
             issue();
         } else {
             if (wh == 0) issue();
@@ -218,7 +245,7 @@ k1_planes_wide_kernel(const _Float16* __restrict__ planes, const _Float16* __res
             comp(I0{});
             comp(I1{});
             comp(integral_constant<int, 2>{});
-            if constexpr (PSA_K1W_POS >= 0 && MTI == PSA_K1W_POS) {
+            if constexpr (PSA_K1W_SOLO == 0 && PSA_K1W_POS >= 0 && MTI == PSA_K1W_POS) {
                 if (wh != 0) issue();
             }
             if constexpr (PSA_K1W_LATE >= 0 && MTI == PSA_K1W_LATE) {
@@ -234,7 +261,7 @@ k1_planes_wide_kernel(const _Float16* __restrict__ planes, const _Float16* __res
         }
         // What this stage read from its own units has been consumed by the MFMAs above (it has returned); the
         // reads still in flight come from stage s+1's units, which nothing overwrites before barrier s+1.
-        asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PENDING) : "memory");
     };
     if constexpr ((PSA_K1W_X & 2) != 0) {
         if (wh) __builtin_amdgcn_s_setprio(1);
