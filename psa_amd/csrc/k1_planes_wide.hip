@@ -37,14 +37,18 @@
 //   8: the next row tile's A fragments are read before the tile's first MFMA (left alone the compiler reads them behind the third)
 //   PSA_K1W_POS p >= 0: the second row half (waves 4-7, the SIMD partners of 0-3) issues its LDS-DMA behind row tile p
 //   instead of at the top of the stage, where its partner is issuing too
-//   PSA_K1W_LATE p >= 0: (s+2, k=4..5) -- the two units that have two stages to land -- are issued behind row tile p
 #ifndef PSA_K1W_POS
 #define PSA_K1W_POS 1       // product build (-2 %; from row tile 3 on the units arrive late: +5 %, +15 % at tile 5)
 #endif
-#ifndef PSA_K1W_LATE
-#define PSA_K1W_LATE -1
-#endif
+// (Issuing part of the LDS-DMA from inside the row-tile sequence -- the units that have two stages to land, or the
+//  loads spread over the stage -- could not be measured: every such build spills 6-300 VGPRs, and scratch traffic
+//  both costs time and breaks the counted vmcnt.  The kernel sits at 250 of 256 registers.)
 //   PSA_K1W_SOLO 1: the first row half (waves 0-3) issues ALL LDS-DMA -- its own units and its SIMD partner's --, waves 4-7 none
+//   PSA_K1W_STAMP 1: DIAGNOSTIC build -- every wavefront of workgroups 0-7 sums s_memtime differences over its stages (top of the
+//   stage -> LDS-DMA issued -> row tile 0 -> tiles 1-3 -> tiles 4-7 -> fold + vmcnt -> barrier) and prints them (cycles per stage)
+#ifndef PSA_K1W_STAMP
+#define PSA_K1W_STAMP 0
+#endif
 #ifndef PSA_K1W_SOLO
 #define PSA_K1W_SOLO 1      // product build (-1.8 % against both halves issuing, the second behind row tile 1)
 #endif
@@ -207,6 +211,23 @@ k1_planes_wide_kernel(const _Float16* __restrict__ planes, const _Float16* __res
 
     // ---- one stage; returns false behind the last one -------------------------------------------------------
     int  left = n_stage;                                                   // stages to go when the period began
+#if PSA_K1W_STAMP
+    unsigned st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0, st_n = 0;
+    auto     stamp_now = [&]() __attribute__((always_inline)) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return (unsigned)t;
+    };
+    auto stamp = [&](int i) __attribute__((always_inline)) {
+        const unsigned t = stamp_now();
+        st_acc[i] += t - st_prev;
+        st_prev = t;
+    };
+    st_prev = stamp_now();
+#define PSA_STAMP(i) stamp(i)
+#else
+#define PSA_STAMP(i)
+#endif
     auto stage = [&](auto s20_c) __attribute__((always_inline)) {
         constexpr int  S20 = decltype(s20_c)::value;
         if constexpr ((PSA_K1W_X & 4) != 0) {
@@ -216,10 +237,9 @@ k1_planes_wide_kernel(const _Float16* __restrict__ planes, const _Float16* __res
         using SN = integral_constant<int, (S20 + 1) % W_PERIOD>;
         using SNN = integral_constant<int, (S20 + 2) % W_PERIOD>;
         // stage s-1's units are free: (s+1, k=6), (s+2, k=0..5)
-        constexpr int EARLY = PSA_K1W_LATE >= 0 ? 4 : 6;
         auto issue = [&]() __attribute__((always_inline)) {
             dma(SN{}, integral_constant<int, 6>{});
-            dma_range(SNN{}, std::make_integer_sequence<int, EARLY>{});
+            dma_range(SNN{}, std::make_integer_sequence<int, 6>{});
         };
         if constexpr (PSA_K1W_SOLO != 0) {
             if (wh == 0) issue();
@@ -228,6 +248,7 @@ k1_planes_wide_kernel(const _Float16* __restrict__ planes, const _Float16* __res
         } else {
             if (wh == 0) issue();
         }
+        PSA_STAMP(0);
         auto tile = [&](auto mt_c) __attribute__((always_inline)) {
             constexpr int MTI = decltype(mt_c)::value, cur = MTI & 1;
             if constexpr (MTI < MT - 1)
@@ -248,11 +269,10 @@ k1_planes_wide_kernel(const _Float16* __restrict__ planes, const _Float16* __res
             if constexpr (PSA_K1W_SOLO == 0 && PSA_K1W_POS >= 0 && MTI == PSA_K1W_POS) {
                 if (wh != 0) issue();
             }
-            if constexpr (PSA_K1W_LATE >= 0 && MTI == PSA_K1W_LATE) {
-                dma(SNN{}, integral_constant<int, 4>{});
-                dma(SNN{}, integral_constant<int, 5>{});
-            }
             __builtin_amdgcn_sched_barrier(0);     // 232 registers are live by design: nothing moves across a row tile
+            if constexpr (MTI == 0) PSA_STAMP(1);
+            if constexpr (MTI == 3) PSA_STAMP(2);
+            if constexpr (MTI == 7) PSA_STAMP(3);
         };
         [&]<int... Ms>(std::integer_sequence<int, Ms...>) __attribute__((always_inline)) { (tile(integral_constant<int, Ms>{}), ...); }(std::make_integer_sequence<int, MT>{});
         if constexpr (folds) fold();
@@ -261,7 +281,15 @@ k1_planes_wide_kernel(const _Float16* __restrict__ planes, const _Float16* __res
         }
         // What this stage read from its own units has been consumed by the MFMAs above (it has returned); the
         // reads still in flight come from stage s+1's units, which nothing overwrites before barrier s+1.
+#if PSA_K1W_STAMP
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PENDING) : "memory");
+        PSA_STAMP(4);
+        asm volatile("s_barrier" ::: "memory");
+        PSA_STAMP(5);
+        ++st_n;
+#else
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PENDING) : "memory");
+#endif
     };
     if constexpr ((PSA_K1W_X & 2) != 0) {
         if (wh) __builtin_amdgcn_s_setprio(1);
@@ -270,6 +298,11 @@ k1_planes_wide_kernel(const _Float16* __restrict__ planes, const _Float16* __res
         [&]<int... Ss>(std::integer_sequence<int, Ss...>) __attribute__((always_inline)) { (stage(integral_constant<int, Ss>{}), ...); }(
             std::make_integer_sequence<int, W_PERIOD>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // nothing in flight when LDS is handed on
+#if PSA_K1W_STAMP
+    if (blockIdx.x < 8 && lane == 0 && st_n)
+        printf("[k1w stamp] block %d wave %d stages %u: dma %u  tile0 %u  tiles1-3 %u  tiles4-7 %u  fold+vmcnt %u  barrier %u  (cycles per stage)\n",
+               (int)blockIdx.x, w, st_n, st_acc[0] / st_n, st_acc[1] / st_n, st_acc[2] / st_n, st_acc[3] / st_n, st_acc[4] / st_n, st_acc[5] / st_n);
+#endif
 
     // ---- epilogue (k1_planes.hip): register j of lane (r16, q) is row 4q + j, column r16 of its 16x16 tile ----
     const int     m0 = mb * W_M_BLK + wh * (W_M_BLK / 2);
