@@ -38,7 +38,7 @@
 //   PSA_K1W_POS p >= 0: the second row half (waves 4-7, the SIMD partners of 0-3) issues its LDS-DMA behind row tile p
 //   instead of at the top of the stage, where its partner is issuing too
 #ifndef PSA_K1W_POS
-#define PSA_K1W_POS 1       // product build (-2 %; from row tile 3 on the units arrive late: +5 %, +15 % at tile 5)
+#define PSA_K1W_POS 1       // product build (-2 %; from row tile 3 on the units arrive late: +5 % at tile 3)
 #endif
 // (Issuing part of the LDS-DMA from inside the row-tile sequence -- the units that have two stages to land, or the
 //  loads spread over the stage -- could not be measured: every such build spills 6-300 VGPRs, and scratch traffic
