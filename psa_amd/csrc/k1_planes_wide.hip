@@ -1,5 +1,6 @@
 // K1 on pre-split planes with a 256-ROW WORKGROUP TILE: the projection GEMM of k1_planes.hip (same
-// "2 x f16" arithmetic, same plane image, same float32-fold rule), for k-lists of more than 64 vectors.
+// "2 x f16" arithmetic, same plane image, same float32-fold rule), for k-lists that fill an even number of
+// 128-row blocks (k1_planes_block_rows).
 //
 // Why: round 3 measured (profiles/r3_k1_experiments.txt, "less LDS-DMA") that what the 128-row kernels
 // wait for is the LDS-DMA pipeline as much as the matrix cores -- a CU takes in a 1-KiB LDS-DMA
@@ -19,10 +20,10 @@
 // ring position (56 s + u) mod 160.  The wavefronts issue the stream in order, wavefront w the units
 // u = 8 k + w (k = 0..6) of every stage: k = 0..2 are the planes (unit 8 c + 4 p + j = component c, piece p,
 // frame group j: a wavefront copies its own frame group's piece h), k = 3..6 the phase tile in the order
-// the row tiles are consumed (unit 24 + 4 mt + 2 h + p).  Entering stage s (barrier s-1 passed; stage s-1's 56 units are free) a wavefront
-// issues (s+1, k=6) and (s+2, k=0..5) (shipped form: waves 0-3 issue their SIMD partners' units too, PSA_K1W_SOLO);
-// the barrier that ends a stage is preceded by vmcnt(2) (SOLO: 4): everything
-// but (s+2, k=4..5) has landed -- all of stage s+1 and the first 32 units of stage s+2, i.e. its planes
+// the row tiles are consumed (unit 24 + 4 mt + 2 h + p).  Entering stage s (barrier s-1 passed; stage s-1's 56
+// units are free) a wavefront issues (s+1, k=6) and (s+2, k=0..5) -- in the shipped form waves 0-3 issue their
+// SIMD partners' units too (PSA_K1W_SOLO); the barrier that ends a stage is preceded by vmcnt(2) (SOLO: 4):
+// everything but (s+2, k=4..5) has landed -- all of stage s+1 and the first 32 units of stage s+2, i.e. its planes
 // and row tiles 0-1, which is what the last row tile of a stage prefetches.  Every unit has at least one
 // stage time (~1.7 us) between issue and first use.  Ring positions repeat every 20 stages (7 blocks of
 // 8 KiB per stage, 20 blocks): the main loop is unrolled 20 times and every LDS address is a constant.
@@ -31,29 +32,33 @@
 
 #include "k1_f16.h"
 
-// Schedule experiments (tools/k1_experiments.sh with KERNEL=k1_planes_wide MACRO=PSA_K1W_X; results stay right):
-//   1: chains folded every 20 stages instead of every 10     2: s_setprio 1 for the second row half (waves 4-7)
-//   4: the stages past the group's last one are skipped instead of multiplying zeros
-//   8: the next row tile's A fragments are read before the tile's first MFMA (left alone the compiler reads them behind the third)
-//   PSA_K1W_POS p >= 0: the second row half (waves 4-7, the SIMD partners of 0-3) issues its LDS-DMA behind row tile p
-//   instead of at the top of the stage, where its partner is issuing too
-#ifndef PSA_K1W_POS
-#define PSA_K1W_POS 1       // product build (-2 %; from row tile 3 on the units arrive late: +5 % at tile 3)
-#endif
-// (Issuing part of the LDS-DMA from inside the row-tile sequence -- the units that have two stages to land, or the
-//  loads spread over the stage -- could not be measured: every such build spills 6-300 VGPRs, and scratch traffic
-//  both costs time and breaks the counted vmcnt.  The kernel sits at 250 of 256 registers.)
-//   PSA_K1W_SOLO 1: the first row half (waves 0-3) issues ALL LDS-DMA -- its own units and its SIMD partner's --, waves 4-7 none
-//   PSA_K1W_STAMP 1: DIAGNOSTIC build -- every wavefront of workgroups 0-7 sums s_memtime differences over its stages (top of the
-//   stage -> LDS-DMA issued -> row tile 0 -> tiles 1-3 -> tiles 4-7 -> fold + vmcnt -> barrier) and prints them (cycles per stage)
-#ifndef PSA_K1W_STAMP
-#define PSA_K1W_STAMP 0
+// Schedule switches (tools/k1_experiments.sh with KERNEL=k1_planes_wide MACRO=PSA_K1W_X, EXTRA_DEFS for the others; results
+// stay right; measurements in profiles/r3_k1_experiments.txt):
+//   PSA_K1W_X bits   1: chains folded every 20 stages instead of every 10 (no gain)   2: s_setprio 1 for waves 4-7 (no gain)
+//                    4: the stages past the group's last one are skipped instead of multiplying zeros (-1 %: configuration 3
+//                       has 1024 stages = 51 periods + 4)
+//                    8: the next row tile's A fragments read before the tile's first MFMA (left alone hipcc reads them behind
+//                       the third and reuses the dead low piece's registers; no gain)
+//   PSA_K1W_SOLO 1   waves 0-3 issue ALL LDS-DMA -- their own units and their SIMD partners' --, waves 4-7 none: a wavefront is
+//                    held ~70 cycles per LDS-DMA instruction, its partner multiplies meanwhile (-1.8 % against the next line)
+//   PSA_K1W_POS p    (SOLO 0) waves 4-7 issue their LDS-DMA behind row tile p instead of at the top of the stage, where their
+//                    partners are issuing too (p = 1: -2 %; p = 3: +5 %, the units arrive late)
+//   PSA_K1W_STAMP 1  DIAGNOSTIC build: every wavefront of workgroups 0-7 sums s_memtime differences over its stages (top of the
+//                    stage -> LDS-DMA issued -> row tile 0 -> tiles 1-3 -> tiles 4-7 -> fold + vmcnt -> barrier) and prints them
+// Issuing part of the LDS-DMA from inside the row-tile sequence (the units that have two stages to land, or the loads spread
+// over the stage) could not be measured: every such build spills 6-300 VGPRs, and scratch traffic both costs time and breaks
+// the counted vmcnt (tests/test_kernel_resources.py guards the product build).  The kernel sits at 250 of 256 registers.
+#ifndef PSA_K1W_X
+#define PSA_K1W_X 4
 #endif
 #ifndef PSA_K1W_SOLO
-#define PSA_K1W_SOLO 1      // product build (-1.8 % against both halves issuing, the second behind row tile 1)
+#define PSA_K1W_SOLO 1
 #endif
-#ifndef PSA_K1W_X
-#define PSA_K1W_X 4       // product build (4 measured -1 %: configuration 3 has 1024 stages = 51 periods + 4)
+#ifndef PSA_K1W_POS
+#define PSA_K1W_POS 1
+#endif
+#ifndef PSA_K1W_STAMP
+#define PSA_K1W_STAMP 0
 #endif
 
 namespace psa {
