@@ -1,6 +1,14 @@
-import sys, numpy as np
-sys.path.insert(0, "/root/repo")
-sys.path.insert(0, "/root/repo/tests")
+#!/usr/bin/env python3
+"""The 256-row form of the planes kernel (PSA_OPT_K1_WIDE) and the 128-row forms against the oracle, before the FFT,
+on a few ragged shapes (GPU box; PSA_HIP_LIBRARY selects a side build of tools/k1_experiments.sh).  The oracle is the
+checker here, as in tests/."""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
 from psa_amd import _hip
 import oracle.psa_oracle as O
 eng = _hip.Engine(0)
