@@ -46,8 +46,13 @@
 //   PSA_K1W_STAMP 1  DIAGNOSTIC build: every wavefront of workgroups 0-7 sums s_memtime differences over its stages (top of the
 //                    stage -> LDS-DMA issued -> row tile 0 -> tiles 1-3 -> tiles 4-7 -> fold + vmcnt -> barrier) and prints them
 // Issuing part of the LDS-DMA from inside the row-tile sequence (the units that have two stages to land, or the loads spread
-// over the stage) could not be measured: every such build spills 6-300 VGPRs, and scratch traffic both costs time and breaks
-// the counted vmcnt (tests/test_kernel_resources.py guards the product build).  The kernel sits at 250 of 256 registers.
+// over the stage) could not be measured: every such build spills 6-350 VGPRs -- any asm statement between the row tiles does
+// it, a C++ branch around a role's loads too -- and scratch traffic both costs time and breaks the counted vmcnt
+// (tests/test_kernel_resources.py guards the product build).  The kernel sits at 248 of 256 registers.
+// Tried with the loads of a role as ONE asm statement that the other role jumps over (no spills): waves 0-3 the ten
+// instructions that have one stage to land at the top of the stage, waves 4-7 the four that have two at its end: +4 %
+// (waves 4-7 are not early at the barrier: from the moment waves 0-3 compute too, the two halves share the matrix pipe);
+// the same split with the loads under an EXEC mask instead of a jump: +13 % (a load under EXEC = 0 still costs its issue).
 #ifndef PSA_K1W_X
 #define PSA_K1W_X 4
 #endif
@@ -310,14 +315,17 @@ k1_planes_wide_kernel(const _Float16* __restrict__ planes, const _Float16* __res
 #endif
 
     // ---- epilogue (k1_planes.hip): register j of lane (r16, q) is row 4q + j, column r16 of its 16x16 tile ----
+    // (the lane's coordinates are taken afresh: carried through the loop they are two more live registers there)
+    const int     lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int     r16_e = lane_e & 15, q_e = lane_e >> 4;
     const int     m0 = mb * W_M_BLK + wh * (W_M_BLK / 2);
-    const int64_t t = (int64_t)tb * W_T_BLK + wf * 16 + r16;
+    const int64_t t = (int64_t)tb * W_T_BLK + wf * 16 + r16_e;
     if (t < T) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
-                const int k = (m0 + mt * 16 + 4 * q + 2 * pr) >> 1;
+                const int k = (m0 + mt * 16 + 4 * q_e + 2 * pr) >> 1;
                 if (k < K) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
