@@ -46,7 +46,7 @@ def rel_max(a, b):
 def golden():
     """All captured reference outputs, keyed like 'coh_all/sed'."""
     out = {}
-    for f in ("calc_cases.npz", "calc_wide.npz", "calc_sym.npz", "kgen_cases.npz", "chiral_cases.npz"):
+    for f in ("calc_cases.npz", "calc_wide.npz", "calc_sym.npz", "calc_w256.npz", "kgen_cases.npz", "chiral_cases.npz"):
         with np.load(GOLDEN / f) as z:
             out.update({k: z[k] for k in z.files})
     return out

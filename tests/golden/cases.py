@@ -148,6 +148,27 @@ CALC_WIDE_CASES = [
 ]
 
 
+# `calculate` cases whose k-lists fill an EVEN number of 128-row blocks (100 k-vectors = 200 rows -> one 256-row block,
+# partly filled; 250 = 500 rows -> two): the territory of the 256-row form of the planes kernel (k1_planes_wide.hip,
+# round 3) -- whole trajectory, index list with duplicates, incoherent type groups, displacement mode and phases of
+# ~200 rad on the triclinic box, a frame count that is no multiple of 64.  (140 k-vectors = three blocks stay on the
+# 128-row form: the cases above.)  Stored like the wide cases.
+_K100 = ("path", [1, 1, 0], 2.0, 100, None)
+_K250 = ("path", "100", 3.0, 250, None)
+CALC_W256_CASES = [
+    dict(name="v_coh_all_k100", traj="a", k=_K100),
+    dict(name="v_coh_all_k250", traj="a", k=_K250),
+    dict(name="v_idx_dup_k100", traj="a", k=_K100,
+         kw=dict(basis_atom_indices=nd([7, 3, 3, 60, 12, 12, 41, 0, 63, 5, 18] + list(range(20, 50))))),
+    dict(name="v_inc_types_nested_k250", traj="a", k=_K250,
+         kw=dict(basis_atom_types=[[1], [2, 3]], summation_mode="incoherent")),
+    dict(name="v_large_phase_k100", traj="b", k=("path", [1, 1, 0], 4.0, 100, None)),
+    dict(name="v_displacements_idx_k250", traj="b", k=("path", "x", 4.0, 250, 2.491), ctor=dict(use_displacements=True),
+         kw=dict(basis_atom_indices=nd(list(range(0, 128, 3)) + [5, 5, 127]))),
+    dict(name="v_nonpow2_T100_k100", traj="c", k=("path", "z", 2.0, 100, None)),
+]
+
+
 # `calculate` cases whose k-lists hold pairs (k, -k) and repeated vectors: the library projects one
 # vector of each pair and writes the partner's columns from it (PSA_OPT_FOLD_PAIRS: S(-k)[w] =
 # conj S(k)[(T-w) mod T]); the REFERENCE computed every vector on its own.  Grids symmetric about

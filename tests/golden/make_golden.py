@@ -68,6 +68,29 @@ def main():
         cx, cy, cz = d["cells"]
         return SEDCalculator(tr, cx, cy, cz, **ctor)
 
+    def wide_fixture(cases, fname):
+        out = {}
+        for case in cases:
+            calc = make_calc(case["traj"], **case.get("ctor", {}))
+            mags, vecs, shape = C.k_from_spec(calc, case["k"])
+            kw = C.realise_kw(case.get("kw", {}))
+            if shape is not None:
+                kw["k_grid_shape"] = shape
+            sed = calc.calculate(mags, vecs, **kw)
+            n = case["name"]
+            out[f"{n}/k_mags"], out[f"{n}/k_vecs"] = mags, vecs
+            out[f"{n}/sed_rows"] = sed.sed[::C.WIDE_SED_STRIDE]
+            out[f"{n}/sed_shape"] = np.array(sed.sed.shape)
+            out[f"{n}/is_complex"] = np.array(sed.is_complex)
+            out[f"{n}/intensity"] = sed.intensity if sed.is_complex else sed.sed
+        np.savez_compressed(HERE / fname, **out)
+        print(f"{fname} {(HERE / fname).stat().st_size / 1024:8.1f} KiB")
+
+    # ---- calculate() on k-lists that fill an even number of 128-row blocks (the 256-row kernel) ------
+    if "--only-w256" in sys.argv:                        # (added in round 3; the other fixtures are unchanged)
+        wide_fixture(C.CALC_W256_CASES, "calc_w256.npz")
+        return
+
     # ---- calculate() on k-lists with (k, -k) pairs and repeated vectors -------------------------
     out = {}
     for case in C.CALC_SYM_CASES:
@@ -87,6 +110,8 @@ def main():
     if "--only-sym" in sys.argv:                         # (added in round 3; the other fixtures are unchanged)
         print(f"calc_sym.npz {(HERE / 'calc_sym.npz').stat().st_size / 1024:8.1f} KiB")
         return
+
+    wide_fixture(C.CALC_W256_CASES, "calc_w256.npz")
 
     # ---- calculate() cases ------------------------------------------------
     out = {}

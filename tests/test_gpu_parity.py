@@ -137,6 +137,20 @@ def test_calculate_wide_matches_reference_golden(case, golden, trajs, engine):
     assert rel_max(again.intensity if again.is_complex else again.sed, golden[f"{name}/intensity"]) <= TOL
 
 
+@pytest.mark.parametrize("case", C.CALC_W256_CASES, ids=[c["name"] for c in C.CALC_W256_CASES])
+def test_calculate_w256_matches_reference_golden(case, golden, trajs, engine):
+    """k-lists that fill an even number of 128-row blocks (100 and 250 vectors): the 256-row form of the planes kernel
+    (k1_planes_wide.hip) held directly to REFERENCE output (tests/golden/calc_w256.npz) -- and the 128-row forms on the
+    same lists (PSA_OPT_K1_WIDE off)."""
+    from psa_amd import _hip
+    test_calculate_wide_matches_reference_golden(case, golden, trajs, engine)
+    engine.set_option(_hip.OPT_K1_WIDE, 0)
+    try:
+        test_calculate_wide_matches_reference_golden(case, golden, trajs, engine)
+    finally:
+        engine.set_option(_hip.OPT_K1_WIDE, 1)
+
+
 @pytest.mark.parametrize("case", C.CALC_SYM_CASES, ids=[c["name"] for c in C.CALC_SYM_CASES])
 def test_calculate_sym_matches_reference_golden(case, golden, trajs, engine):
     """k-lists with (k, -k) pairs and repeated vectors (grids symmetric about Gamma, with and without

@@ -66,6 +66,12 @@ def test_calculate_wide_matches_reference(case, golden, trajs):
     assert rel_max(O.intensity(sed) if is_complex else sed, golden[f"{name}/intensity"]) <= 2e-6
 
 
+@pytest.mark.parametrize("case", C.CALC_W256_CASES, ids=[c["name"] for c in C.CALC_W256_CASES])
+def test_calculate_w256_matches_reference(case, golden, trajs):
+    """100 and 250 k-vectors (the 256-row GPU kernel's territory): the oracle against the reference's output."""
+    test_calculate_wide_matches_reference(case, golden, trajs)
+
+
 @pytest.mark.parametrize("case", C.CALC_SYM_CASES, ids=[c["name"] for c in C.CALC_SYM_CASES])
 def test_calculate_sym_matches_reference(case, golden, trajs):
     """k-lists with (k, -k) pairs and repeated vectors: the oracle (which, like the reference,
